@@ -1,0 +1,279 @@
+"""Golden-vector generator -- runs ONLY in the build container, where /root/reference exists.
+
+Imports the unmodified reference through ``oracle/refshim.py`` (timm stand-in, no-op
+``.cuda()``), fills every floating tensor from the name-seeded RNG of
+``oracle/airnet_oracle.py`` (weights are never stored), runs the reference on seeded
+inputs with DropPath neutralised and stores inputs + outputs as small ``.npz`` files
+(``numpy.load`` with ``allow_pickle=False`` reads them) plus the state-dict schema as JSON.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [unit] [model] [moco] [schema]
+
+A fixture is data (inputs / expected outputs); no reference source text is stored.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import refshim                     # noqa: E402
+import airnet_oracle as O          # noqa: E402
+
+BASE_ARGS = ['--contrast_loss_weight', '0.6', '--degradation_embedding_method', 'all_3_bands',
+             '--de_type', 'denoising_25', 'denoising_25']
+_ARGV = sys.argv[1:]
+opt = refshim.install(BASE_ARGS)
+
+from net.model import AirNet                                   # noqa: E402
+from net import decoder_Uformer as RD                          # noqa: E402
+from net import encoder_Uformer as RE                          # noqa: E402
+from net.utils.frequency_decompose import FrequencyDecompose   # noqa: E402
+from net.utils.leff import LeFF                                # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def rnd(name, shape, scale=1.0):
+    return O.seeded_tensor('input.' + name, shape) / 0.02 * scale
+
+
+def seed_module(mod, prefix):
+    """Fill a reference module from the name-seeded RNG (keys = prefix + state_dict key)."""
+    sd = mod.state_dict()
+    new = {}
+    for k, v in sd.items():
+        tail = k.rsplit('.', 1)[-1]
+        if not v.is_floating_point() or tail == 'mask_freq':
+            new[k] = v
+        elif tail == 'queue':
+            new[k] = torch.nn.functional.normalize(O.seeded_tensor(prefix + k, v.shape) / 0.02, dim=1)
+        else:
+            new[k] = O.seeded_tensor(prefix + k, v.shape)
+    mod.load_state_dict(new)
+    for m in mod.modules():
+        if hasattr(m, 'drop_prob'):
+            m.drop_prob = 0.0
+    return mod
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', name, '%.1f KB' % (os.path.getsize(path) / 1024))
+
+
+def grads_of(mod, loss):
+    for p in mod.parameters():
+        p.grad = None
+    loss.backward()
+    return {k: p.grad for k, p in mod.named_parameters() if p.grad is not None}
+
+
+# ---------------------------------------------------------------------------------------
+def gen_unit():
+    # (i) FrequencyDecompose, all three kinds, inverse True / False / 'visual'
+    for n in (64, 128):
+        x = rnd(f'fd{n}', (1, 2, n, n))
+        out = {'x': x}
+        for kind, size in (('frequency_decompose', 1 / 3.), ('frequency_decompose_1', 0.5),
+                           ('frequency_decompose_dc', 0.5), ('frequency_decompose', 1.0)):
+            for inv in (True, False, 'visual'):
+                if kind == 'frequency_decompose_dc' and inv is not True:
+                    continue
+                fd = FrequencyDecompose(kind, size, n, n, inverse=inv)
+                tag = f'{kind}|{size:.4f}|{inv}'
+                out[tag] = fd(x)
+        save(f'unit_freq_decompose_{n}', **out)
+
+    inter = tuple(rnd(f'inter{i}', (2, 64, 448)) for i in range(3))
+
+    # (ii) decoder WindowAttention with LFS: dims 56/h1, 112/h2; mask on/off; 3 bands / DC
+    for dim, heads in ((56, 1), (112, 2)):
+        for method in ('all_3_bands', 'all_DC'):
+            pre = f'unit_wattn_{dim}_{method}.'
+            wa = seed_module(RD.WindowAttention((16, 16), dim, (8, 8), heads,
+                                                all_degradation_embedding_method=[method]), pre)
+            for use_mask in (False, True):
+                x = rnd(pre + 'x', (8, 64, dim)).requires_grad_(True)
+                it = tuple(t.clone().requires_grad_(True) for t in inter)
+                mask = O.shift_attn_mask(16, 16, 8, 4) if use_mask else None
+                y, _ = wa(x, all_inter=it, mask=mask)
+                w = rnd(pre + 'dy', y.shape)
+                g = grads_of(wa, (y * w).sum())
+                arrs = {'x': x, 'y': y, 'dy': w, 'dx': x.grad}
+                for i in range(1, 3 if method == 'all_3_bands' else 2):
+                    arrs[f'dinter{i}'] = it[i].grad
+                for k, v in g.items():
+                    arrs['g.' + k] = v
+                save(f'unit_wattn_{dim}_{method}_{"mask" if use_mask else "nomask"}', **arrs)
+
+    # (iii) FrequencyWindowAttention intra / inter (L=3 and L=2), with shift mask
+    for L in (3, 2):
+        for kind in ('intra', 'inter'):
+            pre = f'unit_fwattn_{kind}_L{L}.'
+            fa = seed_module(RE.FrequencyWindowAttention(56, (8, 8), 2, type=kind, L=L), pre)
+            for use_mask in (False, True):
+                x = rnd(pre + 'x', (L * 1 * 4, 64, 56)).requires_grad_(True)
+                mask = O.shift_attn_mask(16, 16, 8, 4) if use_mask else None
+                y, _, _ = fa(x, mask=mask)
+                w = rnd(pre + 'dy', y.shape)
+                g = grads_of(fa, (y * w).sum())
+                arrs = {'x': x, 'y': y, 'dy': w, 'dx': x.grad}
+                for k, v in g.items():
+                    arrs['g.' + k] = v
+                save(f'unit_fwattn_{kind}_L{L}_{"mask" if use_mask else "nomask"}', **arrs)
+
+    # (iv) LeFF
+    pre = 'unit_leff.'
+    lf = seed_module(LeFF(56, 224), pre)
+    x = rnd(pre + 'x', (2, 256, 56)).requires_grad_(True)
+    y = lf(x)
+    w = rnd(pre + 'dy', y.shape)
+    g = grads_of(lf, (y * w).sum())
+    arrs = {'x': x, 'y': y, 'dy': w, 'dx': x.grad}
+    arrs.update({'g.' + k: v for k, v in g.items()})
+    save('unit_leff', **arrs)
+
+    # (v) LeWin blocks: decoder (shift 0 / 4), encoder freq (shift 4), encoder origin
+    for shift in (0, 4):
+        pre = f'unit_decblock_s{shift}.'
+        blk = seed_module(RD.LeWinTransformerBlock(112, (16, 16), 2, win_size=8, shift_size=shift,
+                                                   all_degradation_embedding_method=['all_3_bands']), pre)
+        x = rnd(pre + 'x', (2, 256, 112)).requires_grad_(True)
+        y = blk(x, all_inter=inter)
+        w = rnd(pre + 'dy', y.shape)
+        g = grads_of(blk, (y * w).sum())
+        arrs = {'x': x, 'y': y, 'dy': w, 'dx': x.grad}
+        arrs.update({'g.' + k: v for k, v in g.items()})
+        save(f'unit_decblock_s{shift}', **arrs)
+    for msa in ('freq', 'origin'):
+        pre = f'unit_encblock_{msa}.'
+        blk = seed_module(RE.LeWinTransformerBlock(56, (16, 16), 2, win_size=8, shift_size=4,
+                                                   encoder_msa_type=msa, L=3), pre)
+        x = rnd(pre + 'x', (3 * 2, 256, 56)).requires_grad_(True)
+        y, _, _ = blk(x)
+        w = rnd(pre + 'dy', y.shape)
+        g = grads_of(blk, (y * w).sum())
+        arrs = {'x': x, 'y': y, 'dy': w, 'dx': x.grad}
+        arrs.update({'g.' + k: v for k, v in g.items()})
+        save(f'unit_encblock_{msa}', **arrs)
+
+
+def set_opt(**kw):
+    for k, v in kw.items():
+        setattr(opt, k, v)
+
+
+def schema_of(net):
+    return [(k, list(v.shape), str(v.dtype).replace('torch.', '')) for k, v in net.state_dict().items()]
+
+
+def synth_batch(B, size, tag):
+    clean = torch.sigmoid(rnd(tag + 'clean', (B, 3, size, size), 1.5))
+    q = (clean + rnd(tag + 'nq', clean.shape, 25 / 255.)).clamp(0, 1)
+    k = (clean + rnd(tag + 'nk', clean.shape, 25 / 255.)).clamp(0, 1)
+    return clean, q, k
+
+
+def gen_model():
+    variants = {
+        'all3': dict(degradation_embedding_method=['all_3_bands'], L=3, encoder_msa_type='freq'),
+        'allDC': dict(degradation_embedding_method=['all_DC'], L=3, encoder_msa_type='freq'),
+        'all2_L2': dict(degradation_embedding_method=['all_2_bands'], L=2, encoder_msa_type='freq'),
+        'all3_origin': dict(degradation_embedding_method=['all_3_bands'], L=3, encoder_msa_type='origin'),
+    }
+    schemas = {}
+    for name, kw in variants.items():
+        set_opt(batch_size=2, **kw)
+        t0 = time.time()
+        net = seed_module(AirNet(opt), '')
+        for pq, pk in zip(net.E.E.encoder_q.parameters(), net.E.E.encoder_k.parameters()):
+            pk.data.copy_(pq.data)
+        schemas[name] = schema_of(net)
+        clean, q, k = synth_batch(2, 128, 'model.')
+        net.eval()
+        with torch.no_grad():
+            restored_eval = net(x_query=q, x_key=q)
+        arrs = {'restored_eval': restored_eval,
+                'psnr_eval': O.psnr(restored_eval, clean), 'psnr_input': O.psnr(q, clean)}
+        if name in ('all3', 'all2_L2'):
+            net.train()
+            restored, logits, labels = net(x_query=q, x_key=k)
+            CE = torch.nn.CrossEntropyLoss()
+            contrast = sum(CE(logits[i], labels[i]) for i in range(opt.L)) / opt.L
+            l1 = torch.nn.L1Loss()(restored, clean)
+            loss = l1 + opt.contrast_loss_weight * contrast
+            g = grads_of(net, loss)
+            names = sorted(g.keys())
+            arrs.update({'restored_train': restored, 'logits': torch.stack(logits, 0),
+                         'loss': loss, 'l1': l1, 'contrast': contrast,
+                         'grad_names': np.array(names), 'grad_norms': np.array([g[n].norm().item() for n in names]),
+                         'queue_after': net.E.E.queue, 'queue_ptr_after': net.E.E.queue_ptr})
+            for n in names:
+                if g[n].numel() <= 4096 and ('blocks.0.' in n or 'mlp.' in n):
+                    arrs['g.' + n] = g[n]
+            for n in ('R.R.output_proj.proj.0.weight', 'R.R.input_proj.proj.0.weight',
+                      'E.E.encoder_q.uformer.input_proj.proj.0.weight'):
+                arrs['g.' + n] = g[n]
+            bn = net.E.E.encoder_q.norm[0][0]
+            arrs['bn_q0_running_mean'] = bn.running_mean
+            arrs['bn_q0_running_var'] = bn.running_var
+            arrs['bn_k0_running_mean'] = net.E.E.encoder_k.norm[0][0].running_mean
+        save(f'model_{name}', **arrs)
+        print(name, 'done in %.1fs' % (time.time() - t0))
+        del net
+    with open(os.path.join(HERE, 'schema.json'), 'w') as f:
+        json.dump(schemas, f)
+
+
+def gen_moco():
+    """Three consecutive train-mode steps of the encoder side only (net.E), SGD lr 0.05 on the
+    query encoder in between, so that EMA, queue rotation and pointer wrap are all exercised."""
+    set_opt(batch_size=2, degradation_embedding_method=['all_3_bands'], L=3, encoder_msa_type='freq')
+    net = seed_module(AirNet(opt), '')
+    for pq, pk in zip(net.E.E.encoder_q.parameters(), net.E.E.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    net.train()
+    arrs = {}
+    CE = torch.nn.CrossEntropyLoss()
+    probe = ['uformer.input_proj.proj.0.weight', 'mlp.0.2.weight', 'uformer.conv.blocks.1.mlp.linear2.0.bias']
+    for step in range(4):
+        _, q, k = synth_batch(2, 128, f'moco{step}.')
+        _, logits, labels, inter = net.E(x_query=q, x_key=k)
+        loss = sum(CE(logits[i], labels[i]) for i in range(3)) / 3
+        for p in net.parameters():
+            p.grad = None
+        loss.backward()
+        with torch.no_grad():
+            for p in net.E.E.encoder_q.parameters():
+                if p.grad is not None:
+                    p -= 0.05 * p.grad
+        arrs[f'logits{step}'] = torch.stack(logits, 0)
+        arrs[f'loss{step}'] = loss
+        arrs[f'queue{step}'] = net.E.E.queue.clone()
+        arrs[f'ptr{step}'] = net.E.E.queue_ptr.clone()
+        ksd = net.E.E.encoder_k.state_dict()
+        for n in probe:
+            arrs[f'k{step}.' + n] = ksd[n].clone()
+    save('moco_steps', **arrs)
+
+
+if __name__ == '__main__':
+    what = _ARGV or ['unit', 'model', 'moco']
+    with torch.enable_grad():
+        if 'unit' in what:
+            gen_unit()
+        if 'model' in what:
+            gen_model()
+        if 'moco' in what:
+            gen_moco()

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build the C-ABI HIP library for gfx950 (MI355X) in-tree.  Usage: ./build.sh
+set -e
+cd "$(dirname "$0")/csrc"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value"
+mkdir -p ../build
+pids=()
+for f in fw_gemm fw_norm fw_attn fw_elem fw_heads; do
+  if [ ! -f ../build/$f.o ] || [ $f.hip -nt ../build/$f.o ] || [ fw_common.h -nt ../build/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o ../build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC ../build/fw_gemm.o ../build/fw_norm.o ../build/fw_attn.o ../build/fw_elem.o ../build/fw_heads.o -o ../libfwair_hip.so
+echo "built $(cd ..; pwd)/libfwair_hip.so"

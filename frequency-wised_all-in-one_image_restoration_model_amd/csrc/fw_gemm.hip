@@ -1,0 +1,319 @@
+// fw_gemm: the one GEMM of the AirNet hot path (K3/K4/K7/K8 of SURVEY.md section 2.2).
+//
+//   C[m][n] = epilogue( alpha * sum_k X(m,k) * W(n,k) )
+//
+// Replaces the reference's nn.Linear forward/backward (decoder_Uformer.py:98-125 LinearProjection,
+// :294 proj, net/utils/leff.py:100,114 linear1/linear2, encoder_Uformer.py:942 mlp_head) and, with
+// the im2col helpers of fw_elem.hip, its k4s2 / k2s2 convolutions (decoder_Uformer.py:414-449).
+//
+// MI355X design: 256 threads = 4 waves per workgroup, one 128(m) x BN(n) output tile, K walked in
+// 128-byte steps (64 bf16 / 32 f32) through a double-buffered, register-staged LDS pipeline with
+// one barrier per step.  Both operands are held in LDS k-contiguous ([row][k], 144-byte padded
+// rows).  An operand whose reduction index is the SLOW axis in HBM (dX = dY*W, dW = dY^T*X) is
+// transposed in registers while it is staged (16-byte loads along the fast axis, v_perm_b32 /
+// register renaming, 8- or 16-byte LDS writes), so one MFMA inner loop serves NT, NN and TN.
+// The MFMA roles are swapped (A-operand = W rows, B-operand = X rows) so that a lane ends up
+// with 4 CONSECUTIVE n for one m: bias / residual / output are 8- and 16-byte vector accesses.
+// bf16 uses v_mfma_f32_16x16x32_bf16, f32 uses v_mfma_f32_16x16x4_f32 (exact f32), same code.
+#include "fw_common.h"
+
+namespace {
+
+struct GemmArgs {
+    const char* X; const char* W; char* C;
+    long ldx, ldw, ldc;                 // elements
+    int M, N, K;
+    int x_op, w_op;                     // 1: GELU applied to the operand while staging
+    const float* bias;                  // [N] or null
+    int act; float slope;               // 1: leaky relu   2: times gelu'(aux)   3: gelu
+    const char* aux; long ldaux;        // T [M][ldaux]
+    const float* rowscale; int rows_per_scale;
+    const float* residual; long ldr;    // f32 [M][ldr]
+    int out_f32;                        // C is float (else T)
+    int accumulate;                     // 0 store, 1 atomicAdd (f32 C only)
+    int splitk; int kper;               // K range per z-slice (multiple of the K step)
+    float alpha;
+};
+
+constexpr int LDS_ROW = 144;            // 128 B of K + 16 B pad
+constexpr int BM = 128;
+
+template <typename T> FW_DEV uint4 apply_gelu16(const uint4& v) {
+    float f[TT<T>::E16];
+    unpack16<T>(v, f);
+#pragma unroll
+    for (int i = 0; i < TT<T>::E16; ++i) f[i] = gelu_f(f[i]);
+    return pack16<T>(f);
+}
+
+// ---- operand staging -----------------------------------------------------------------------
+// DIRECT: element (i, k) at base + i*ld + k.   ROWS rows x 8 chunks of 16 B.
+template <typename T, int ROWS>
+struct StageDirect {
+    static constexpr int NL = ROWS / 32;
+    uint4 r[NL];
+    FW_MEM void load(const char* base, long ld, int row0, int rows_total, int kbyte0, int kbytes_end, int op) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int t = 0; t < NL; ++t) {
+            const int cid = tid + 256 * t;
+            const int row = cid >> 3, ch = cid & 7;
+            const int kb = kbyte0 + ch * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row0 + row < rows_total && kb < kbytes_end) {
+                v = *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * ld * TT<T>::SZ + kb);
+                if (op == 1) v = apply_gelu16<T>(v);
+                const int valid = kbytes_end - kb;          // K*sizeof(T) need only be a multiple of 4 bytes
+                if (valid < 16) {
+                    if (valid <= 12) v.w = 0;
+                    if (valid <= 8) v.z = 0;
+                    if (valid <= 4) v.y = 0;
+                }
+            }
+            r[t] = v;
+        }
+    }
+    FW_MEM void store(char* tile) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int t = 0; t < NL; ++t) {
+            const int cid = tid + 256 * t;
+            *reinterpret_cast<uint4*>(tile + (cid >> 3) * LDS_ROW + (cid & 7) * 16) = r[t];
+        }
+    }
+};
+
+// TRANS: element (i, k) at base + k*ld + i  (i contiguous).  A thread owns a 4(k) x E(i) block.
+template <typename T, int ROWS>
+struct StageTrans {
+    static constexpr int E = TT<T>::E16;
+    static constexpr int IB = ROWS / E;                 // i-blocks per tile
+    static constexpr int KT = 128 / TT<T>::SZ;          // k elements per step
+    static constexpr int NTHR = IB * (KT / 4);          // active threads (256 or 128)
+    uint4 r[4];
+    FW_MEM void load(const char* base, long ld, int row0, int rows_total, int k0, int k_end, int op) {
+        const int tid = threadIdx.x;
+        const int ib = tid % IB, kb = tid / IB;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = k0 + kb * 4 + kk;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (tid < NTHR && k < k_end && row0 + ib * E < rows_total) {
+                v = *reinterpret_cast<const uint4*>(base + ((long)k * ld + row0 + ib * E) * TT<T>::SZ);
+                if (op == 1) v = apply_gelu16<T>(v);
+            }
+            r[kk] = v;
+        }
+    }
+    FW_MEM void store(char* tile) const {
+        const int tid = threadIdx.x;
+        if (tid >= NTHR) return;
+        const int ib = tid % IB, kb = tid / IB;
+        if constexpr (sizeof(T) == 4) {
+            char* p = tile + (ib * 4) * LDS_ROW + kb * 16;
+            *reinterpret_cast<uint4*>(p) = make_uint4(r[0].x, r[1].x, r[2].x, r[3].x);
+            *reinterpret_cast<uint4*>(p + LDS_ROW) = make_uint4(r[0].y, r[1].y, r[2].y, r[3].y);
+            *reinterpret_cast<uint4*>(p + 2 * LDS_ROW) = make_uint4(r[0].z, r[1].z, r[2].z, r[3].z);
+            *reinterpret_cast<uint4*>(p + 3 * LDS_ROW) = make_uint4(r[0].w, r[1].w, r[2].w, r[3].w);
+        } else {
+            char* p = tile + (ib * 8) * LDS_ROW + kb * 8;
+            const unsigned w0[4] = {r[0].x, r[0].y, r[0].z, r[0].w};
+            const unsigned w1[4] = {r[1].x, r[1].y, r[1].z, r[1].w};
+            const unsigned w2[4] = {r[2].x, r[2].y, r[2].z, r[2].w};
+            const unsigned w3[4] = {r[3].x, r[3].y, r[3].z, r[3].w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                // element e = 2d (low halves) and e = 2d+1 (high halves) of the four k-rows
+                uint2 lo = make_uint2(__builtin_amdgcn_perm(w1[d], w0[d], 0x05040100u),
+                                      __builtin_amdgcn_perm(w3[d], w2[d], 0x05040100u));
+                uint2 hi = make_uint2(__builtin_amdgcn_perm(w1[d], w0[d], 0x07060302u),
+                                      __builtin_amdgcn_perm(w3[d], w2[d], 0x07060302u));
+                *reinterpret_cast<uint2*>(p + (2 * d) * LDS_ROW) = lo;
+                *reinterpret_cast<uint2*>(p + (2 * d + 1) * LDS_ROW) = hi;
+            }
+        }
+    }
+};
+
+template <typename T, int ROWS, bool TRANS> struct Stage;
+template <typename T, int ROWS> struct Stage<T, ROWS, false> : StageDirect<T, ROWS> {
+    FW_MEM void fetch(const char* base, long ld, int row0, int rows_total, int k0, int k_end, int op) {
+        this->load(base, ld, row0, rows_total, k0 * TT<T>::SZ, k_end * TT<T>::SZ, op);
+    }
+};
+template <typename T, int ROWS> struct Stage<T, ROWS, true> : StageTrans<T, ROWS> {
+    FW_MEM void fetch(const char* base, long ld, int row0, int rows_total, int k0, int k_end, int op) {
+        this->load(base, ld, row0, rows_total, k0, k_end, op);
+    }
+};
+
+template <typename T, int BN, bool XT, bool WT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+    constexpr int KT = 128 / TT<T>::SZ;                  // k elements per step
+    constexpr int WM = (BN == 128) ? 4 : 2;              // m tiles (16) per wave
+    constexpr int XBYTES = BM * LDS_ROW, WBYTES = BN * LDS_ROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto xs = [&](int i) -> char* { return smem + i * (XBYTES + WBYTES); };
+    auto ws = [&](int i) -> char* { return smem + i * (XBYTES + WBYTES) + XBYTES; };
+
+    const int wave = threadIdx.x >> 6;
+    const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+    const int wm0 = (BN == 128) ? (wave & 1) * 64 : wave * 32;
+    const int wn0 = (BN == 128) ? (wave >> 1) * 64 : 0;
+
+    const int k_begin = blockIdx.z * a.kper;
+    const int k_end = min(a.K, k_begin + a.kper);
+    const int nsteps = (k_end - k_begin + KT - 1) / KT;
+
+    f32x4 acc[4][WM];                                    // [n tile][m tile]: rows = n, cols = m
+    zero_acc(acc);
+
+    Stage<T, BM, XT> sx;
+    Stage<T, BN, WT> sw;
+    if (nsteps > 0) {
+        sx.fetch(a.X, a.ldx, m_blk, a.M, k_begin, k_end, a.x_op);
+        sw.fetch(a.W, a.ldw, n_blk, a.N, k_begin, k_end, a.w_op);
+        sx.store(xs(0));
+        sw.store(ws(0));
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nsteps) {
+            sx.fetch(a.X, a.ldx, m_blk, a.M, k_begin + (s + 1) * KT, k_end, a.x_op);
+            sw.fetch(a.W, a.ldw, n_blk, a.N, k_begin + (s + 1) * KT, k_end, a.w_op);
+        }
+        mma_tiles<T, 4, WM>(acc, ws(cur), LDS_ROW, wn0, xs(cur), LDS_ROW, wm0, 2);
+        if (s + 1 < nsteps) {
+            sx.store(xs(cur ^ 1));
+            sw.store(ws(cur ^ 1));
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m][n0..n0+3], m = col of the MFMA tile, n = rows -------------
+    const int l = lane_id();
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        const int m = m_blk + wm0 + mt * 16 + (l & 15);
+        if (m >= a.M) continue;
+        const float rs = a.rowscale ? a.rowscale[m / a.rows_per_scale] : 1.0f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+            if (n0 >= a.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[nt][mt][r] * a.alpha;
+            if (a.bias && blockIdx.z == 0) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += b[r];
+            }
+            if (a.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = lrelu_f(v[r], a.slope);
+            } else if (a.act == 2) {
+                const T* ap = reinterpret_cast<const T*>(a.aux) + (long)m * a.ldaux + n0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(TT<T>::ld(ap + r));
+            } else if (a.act == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            }
+            if (a.rowscale) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= rs;
+            }
+            if (a.residual && blockIdx.z == 0) {
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(a.residual + (long)m * a.ldr + n0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rr[r];
+            }
+            if (a.out_f32) {
+                float* cp = reinterpret_cast<float*>(a.C) + (long)m * a.ldc + n0;
+                if (a.accumulate) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
+                } else {
+                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                }
+            } else {
+                T* cp = reinterpret_cast<T*>(a.C) + (long)m * a.ldc + n0;
+                if (sizeof(T) == 4) {
+                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BN, bool XT, bool WT>
+int launch(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, BN, XT, WT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid(fw_cdiv(a.M, BM), fw_cdiv(a.N, BN), a.splitk);
+    hipLaunchKernelGGL((gemm_kernel<T, BN, XT, WT>), grid, dim3(256), lds, st, a);
+    FW_LAUNCH_RET();
+}
+
+template <typename T, int BN>
+int dispatch_trans(const GemmArgs& a, int xt, int wt, hipStream_t st) {
+    if (!xt && !wt) return launch<T, BN, false, false>(a, st);
+    if (!xt && wt) return launch<T, BN, false, true>(a, st);
+    if (xt && !wt) return launch<T, BN, true, false>(a, st);
+    return launch<T, BN, true, true>(a, st);
+}
+
+}  // namespace
+
+// C-ABI.  Declared in include/fwair.h.
+extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op, const void* W, long ldw,
+                       int w_trans, int w_op, void* C, long ldc, int out_f32, int accumulate, int M, int N,
+                       int K, float alpha, const float* bias, int act, float slope, const void* aux,
+                       long ldaux, const float* rowscale, int rows_per_scale, const float* residual,
+                       long ldr, int splitk, void* stream) {
+    const int sz = dtype == FW_DT_BF16 ? 2 : 4;
+    const int e16 = 16 / sz;
+    FW_CHECK_ARG(dtype == FW_DT_F32 || dtype == FW_DT_BF16);
+    FW_CHECK_ARG(M > 0 && N > 0 && K > 0 && X && W && C);
+    FW_CHECK_ARG(N % 4 == 0);
+    FW_CHECK_ARG(ldx % e16 == 0 && ldw % e16 == 0 && ldc % 4 == 0);
+    const int csz = (out_f32 || dtype == FW_DT_F32) ? 4 : 2;
+    FW_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & (4 * csz - 1)) == 0);
+    if (!x_trans) FW_CHECK_ARG((K * sz) % 4 == 0 && ldx >= K); else FW_CHECK_ARG(ldx >= M);
+    if (!w_trans) FW_CHECK_ARG((K * sz) % 4 == 0 && ldw >= K); else FW_CHECK_ARG(ldw >= N);
+    FW_CHECK_ARG(!accumulate || out_f32 || dtype == FW_DT_F32);
+    FW_CHECK_ARG(splitk >= 1 && (splitk == 1 || accumulate));
+    FW_CHECK_ARG(act >= 0 && act <= 3 && (act != 2 || aux));
+    FW_CHECK_ARG(!rowscale || rows_per_scale > 0);
+    if (bias) FW_CHECK_ARG(((uintptr_t)bias & 15) == 0);
+    if (residual) FW_CHECK_ARG(((uintptr_t)residual & 15) == 0 && ldr % 4 == 0);
+    const int kt = 128 / sz;
+    GemmArgs a;
+    a.X = (const char*)X; a.W = (const char*)W; a.C = (char*)C;
+    a.ldx = ldx; a.ldw = ldw; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.x_op = x_op; a.w_op = w_op; a.bias = bias; a.act = act; a.slope = slope;
+    a.aux = (const char*)aux; a.ldaux = ldaux; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale;
+    a.residual = residual; a.ldr = ldr;
+    a.out_f32 = (out_f32 || dtype == FW_DT_F32) ? 1 : 0;
+    a.accumulate = accumulate;
+    a.splitk = splitk;
+    a.kper = fw_cdiv(fw_cdiv(K, kt), splitk) * kt;
+    a.alpha = alpha;
+    hipStream_t st = (hipStream_t)stream;
+    const bool small_n = N <= 64;
+    if (dtype == FW_DT_BF16) {
+        return small_n ? dispatch_trans<bf16raw, 64>(a, x_trans, w_trans, st)
+                       : dispatch_trans<bf16raw, 128>(a, x_trans, w_trans, st);
+    }
+    return small_n ? dispatch_trans<float, 64>(a, x_trans, w_trans, st)
+                   : dispatch_trans<float, 128>(a, x_trans, w_trans, st);
+}

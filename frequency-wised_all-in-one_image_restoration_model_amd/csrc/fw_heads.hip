@@ -1,0 +1,526 @@
+// Small-tensor kernels of the AirNet hot path:
+//   * image band decomposition by partial 2-D DFT (K6; net/utils/frequency_decompose.py:28-118)
+//   * encoder contrastive head: BatchNorm2d(batch stats) + LeakyReLU(0.1) + global average pool,
+//     forward and backward (K8; net/encoder_Uformer.py:945-951,978-984)
+//   * MoCo logits / enqueue (K9; net/utils/moco.py:127-164)
+//   * the learned-frequency-selection lambda heads of ALL decoder blocks in one launch
+//     (K12; net/decoder_Uformer.py:178-193,279-284)
+// These are latency/bandwidth trivia next to the GEMMs; they exist so that no arithmetic of the
+// training step is left to a library.
+#include "fw_common.h"
+
+namespace {
+
+template <int N> FW_DEV float block_sum(float v, float* red) {      // N threads, N multiple of 64
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane_id() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < N / 64; ++i) s += red[i];
+    return s;
+}
+
+// =====================================================================================================
+// 2-D DFT band decomposition, one image per workgroup, N <= 128
+// =====================================================================================================
+// spectrum (unshifted) F[u][v] = sum_{y,x} img[y][x] exp(-2 pi i (u y + v x) / N)  ->  fr, fi [n][N][N]
+__global__ __launch_bounds__(256) void dft2_fwd_kernel(const float* __restrict__ img, float* __restrict__ fr, float* __restrict__ fi, int N) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* gr = sm;                 // [N][N]  G[y][v] real
+    float* gi = sm + N * N;         // imag
+    float* tc = sm + 2 * N * N;     // cos(2 pi k / N)
+    float* ts = tc + N;             // sin
+    const float* x = img + (size_t)blockIdx.x * N * N;
+    for (int k = threadIdx.x; k < N; k += 256) { float s, c; sincospif(2.0f * k / N, &s, &c); tc[k] = c; ts[k] = s; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < N * N; o += 256) {          // rows: G[y][v] = sum_x img[y][x] e^{-i 2pi x v/N}
+        const int y = o / N, v = o % N;
+        float ar = 0.f, ai = 0.f;
+        for (int xx = 0; xx < N; ++xx) {
+            const float p = x[y * N + xx];
+            const int k = (xx * v) & (N - 1);
+            ar += p * tc[k]; ai -= p * ts[k];
+        }
+        gr[o] = ar; gi[o] = ai;
+    }
+    __syncthreads();
+    float* outr = fr + (size_t)blockIdx.x * N * N;
+    float* outi = fi + (size_t)blockIdx.x * N * N;
+    for (int o = threadIdx.x; o < N * N; o += 256) {          // cols: F[u][v] = sum_y G[y][v] e^{-i 2pi y u/N}
+        const int u = o / N, v = o % N;
+        float ar = 0.f, ai = 0.f;
+        for (int y = 0; y < N; ++y) {
+            const int k = (y * u) & (N - 1);
+            const float c = tc[k], s = ts[k], a = gr[y * N + v], b = gi[y * N + v];
+            ar += a * c + b * s; ai += b * c - a * s;
+        }
+        outr[o] = ar; outi[o] = ai;
+    }
+}
+// band image: out[band][n][y][x] = Re( IDFT2( mask_band * F ) ),  mask in UNSHIFTED coordinates [nb][N][N]
+__global__ __launch_bounds__(256) void dft2_band_inv_kernel(const float* __restrict__ fr, const float* __restrict__ fi, const float* __restrict__ mask,
+                                                            float* __restrict__ out, int N, int nimg) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* hr = sm; float* hi = sm + N * N; float* tc = sm + 2 * N * N; float* ts = tc + N;
+    const int n = blockIdx.x, band = blockIdx.y;
+    const float* Fr = fr + (size_t)n * N * N; const float* Fi = fi + (size_t)n * N * N;
+    const float* M = mask + (size_t)band * N * N;
+    for (int k = threadIdx.x; k < N; k += 256) { float s, c; sincospif(2.0f * k / N, &s, &c); tc[k] = c; ts[k] = s; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < N * N; o += 256) {          // H[u][x] = sum_v M F[u][v] e^{+i 2pi v x/N}
+        const int u = o / N, xx = o % N;
+        float ar = 0.f, ai = 0.f;
+        for (int v = 0; v < N; ++v) {
+            const float m = M[u * N + v];
+            if (m == 0.f) continue;
+            const int k = (v * xx) & (N - 1);
+            const float c = tc[k], s = ts[k], a = Fr[u * N + v], b = Fi[u * N + v];
+            ar += a * c - b * s; ai += a * s + b * c;
+        }
+        hr[o] = ar; hi[o] = ai;
+    }
+    __syncthreads();
+    float* o_ = out + ((size_t)band * nimg + n) * N * N;
+    const float inv = 1.0f / (N * N);
+    for (int o = threadIdx.x; o < N * N; o += 256) {          // out[y][x] = Re sum_u H[u][x] e^{+i 2pi u y/N} / N^2
+        const int y = o / N, xx = o % N;
+        float ar = 0.f;
+        for (int u = 0; u < N; ++u) {
+            const int k = (u * y) & (N - 1);
+            ar += hr[u * N + xx] * tc[k] - hi[u * N + xx] * ts[k];
+        }
+        o_[o] = ar * inv;
+    }
+}
+// masked spectrum: mode 0 -> (re, im) interleaved, unshifted (inverse == False);  mode 1 -> |.| in fftshift-ed coordinates ('visual')
+__global__ void dft2_band_spec_kernel(const float* __restrict__ fr, const float* __restrict__ fi, const float* __restrict__ mask,
+                                      float* __restrict__ out, int N, int nimg, int mode) {
+    const int n = blockIdx.x, band = blockIdx.y;
+    const float* Fr = fr + (size_t)n * N * N; const float* Fi = fi + (size_t)n * N * N;
+    const float* M = mask + (size_t)band * N * N;
+    for (int o = threadIdx.x; o < N * N; o += 256) {
+        const float m = M[o], a = Fr[o] * m, b = Fi[o] * m;
+        if (mode == 0) {
+            float* d = out + (((size_t)band * nimg + n) * N * N + o) * 2;
+            d[0] = a; d[1] = b;
+        } else {
+            const int u = o / N, v = o % N;
+            const int us = (u + N / 2) & (N - 1), vs = (v + N / 2) & (N - 1);
+            out[((size_t)band * nimg + n) * N * N + us * N + vs] = sqrtf(a * a + b * b);
+        }
+    }
+}
+// DC split (frequency_decompose_dc): out[0] = mean, out[1] = x - mean
+__global__ __launch_bounds__(256) void dc_split_kernel(const float* __restrict__ img, float* __restrict__ out, int NN, int nimg) {
+    __shared__ float red[4];
+    const float* x = img + (size_t)blockIdx.x * NN;
+    float s = 0.f;
+    for (int o = threadIdx.x; o < NN; o += 256) s += x[o];
+    const float mean = block_sum<256>(s, red) / NN;
+    float* o0 = out + (size_t)blockIdx.x * NN; float* o1 = out + ((size_t)nimg + blockIdx.x) * NN;
+    for (int o = threadIdx.x; o < NN; o += 256) { o0[o] = mean; o1[o] = x[o] - mean; }
+}
+
+// =====================================================================================================
+// encoder head: BatchNorm2d + LeakyReLU(0.1) + global average pool over fea viewed as [B][ED][P]
+// =====================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ fea, float* __restrict__ part, int B, int ED, int P) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const T* x = fea + ((size_t)b * ED + c) * P;
+    float s = 0.f, q = 0.f;
+    for (int o = threadIdx.x; o < P; o += 256) { const float v = TT<T>::ld(x + o); s += v; q += v * v; }
+    s = block_sum<256>(s, red); q = block_sum<256>(q, red);
+    if (threadIdx.x == 0) { part[((size_t)c * B + b) * 2] = s; part[((size_t)c * B + b) * 2 + 1] = q; }
+}
+// training: stats from `part`; eval: running stats.  gap[b][c] = mean_p lrelu(bn(x)).  Block (c, 0) updates the running stats.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_gap_kernel(const T* __restrict__ fea, const float* __restrict__ part, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                           long long* __restrict__ nbt, float* __restrict__ gap, float* __restrict__ saved, int B,
+                                                           int ED, int P, int training, float eps, float mom, float slope) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    float mean, var;
+    if (training) {
+        float s = 0.f, q = 0.f;
+        for (int i = 0; i < B; ++i) { s += part[((size_t)c * B + i) * 2]; q += part[((size_t)c * B + i) * 2 + 1]; }
+        const float n = (float)B * P;
+        mean = s / n; var = fmaxf(q / n - mean * mean, 0.f);
+        if (b == 0 && threadIdx.x == 0) {
+            rmean[c] = (1.f - mom) * rmean[c] + mom * mean;
+            rvar[c] = (1.f - mom) * rvar[c] + mom * var * n / (n - 1.f);
+            if (c == 0) *nbt += 1;
+            saved[c * 2] = mean; saved[c * 2 + 1] = rsqrtf(var + eps);
+        }
+    } else { mean = rmean[c]; var = rvar[c]; }
+    const float rs = rsqrtf(var + eps), g = gamma[c], be = beta[c];
+    const T* x = fea + ((size_t)b * ED + c) * P;
+    float s = 0.f;
+    for (int o = threadIdx.x; o < P; o += 256) s += lrelu_f((TT<T>::ld(x + o) - mean) * rs * g + be, slope);
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) gap[(size_t)b * ED + c] = s / P;
+}
+// backward pass 1: dy = dgap[b][c]/P * lrelu'(z); part2[c][b] = (sum dy, sum dy*xhat)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__ fea, const float* __restrict__ saved, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ dgap, float* __restrict__ part2,
+                                                           int B, int ED, int P, float slope) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float mean = saved[c * 2], rs = saved[c * 2 + 1], g = gamma[c], be = beta[c];
+    const float dg = dgap[(size_t)b * ED + c] / P;
+    const T* x = fea + ((size_t)b * ED + c) * P;
+    float s = 0.f, q = 0.f;
+    for (int o = threadIdx.x; o < P; o += 256) {
+        const float xh = (TT<T>::ld(x + o) - mean) * rs;
+        const float dy = (xh * g + be > 0.f) ? dg : dg * slope;
+        s += dy; q += dy * xh;
+    }
+    s = block_sum<256>(s, red); q = block_sum<256>(q, red);
+    if (threadIdx.x == 0) { part2[((size_t)c * B + b) * 2] = s; part2[((size_t)c * B + b) * 2 + 1] = q; }
+}
+// backward pass 2: dx = g*rs*(dy - mean(dy) - xhat*mean(dy*xhat)) -> T;  dgamma/dbeta += (block b == 0)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ fea, const float* __restrict__ saved, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ dgap, const float* __restrict__ part2,
+                                                           T* __restrict__ dfea, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int ED,
+                                                           int P, float slope) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float mean = saved[c * 2], rs = saved[c * 2 + 1], g = gamma[c], be = beta[c];
+    float s = 0.f, q = 0.f;
+    for (int i = 0; i < B; ++i) { s += part2[((size_t)c * B + i) * 2]; q += part2[((size_t)c * B + i) * 2 + 1]; }
+    if (b == 0 && threadIdx.x == 0) { atomicAdd(dbeta + c, s); atomicAdd(dgamma + c, q); }
+    const float n = (float)B * P, m1 = s / n, m2 = q / n;
+    const float dg = dgap[(size_t)b * ED + c] / P;
+    const T* x = fea + ((size_t)b * ED + c) * P;
+    T* d = dfea + ((size_t)b * ED + c) * P;
+    for (int o = threadIdx.x; o < P; o += 256) {
+        const float xh = (TT<T>::ld(x + o) - mean) * rs;
+        const float dy = (xh * g + be > 0.f) ? dg : dg * slope;
+        TT<T>::st(d + o, g * rs * (dy - m1 - xh * m2));
+    }
+}
+
+// =====================================================================================================
+// MoCo: normalise, logits = [q.k, q.queue] / T, backward to q, enqueue
+// =====================================================================================================
+// grid (L, B), 256 threads.  q, k: [L][B][ED] (un-normalised).  queue: [L][ED][K].  logits: [L][B][1+K].  khat: [L][B][ED].
+__global__ __launch_bounds__(256) void moco_logits_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ queue,
+                                                          float* __restrict__ logits, float* __restrict__ khat, int B, int ED, int K, float invT) {
+    __shared__ float red[4];
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // qh[ED]
+    const int l = blockIdx.x, b = blockIdx.y;
+    const float* qq = q + ((size_t)l * B + b) * ED; const float* kk = k + ((size_t)l * B + b) * ED;
+    float sq = 0.f, sk = 0.f;
+    for (int c = threadIdx.x; c < ED; c += 256) { sq += qq[c] * qq[c]; sk += kk[c] * kk[c]; }
+    sq = block_sum<256>(sq, red); sk = block_sum<256>(sk, red);
+    const float iq = 1.f / fmaxf(sqrtf(sq), 1e-12f), ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);
+    float pos = 0.f;
+    for (int c = threadIdx.x; c < ED; c += 256) {
+        const float a = qq[c] * iq, bb = kk[c] * ik;
+        sm[c] = a; khat[((size_t)l * B + b) * ED + c] = bb; pos += a * bb;
+    }
+    pos = block_sum<256>(pos, red);
+    float* lg = logits + ((size_t)l * B + b) * (1 + K);
+    if (threadIdx.x == 0) lg[0] = pos * invT;
+    const float* Q = queue + (size_t)l * ED * K;
+    for (int j = threadIdx.x; j < K; j += 256) {
+        float s = 0.f;
+        for (int c = 0; c < ED; ++c) s += sm[c] * Q[(size_t)c * K + j];
+        lg[1 + j] = s * invT;
+    }
+}
+// dq[l][b][c] from dlogits; queue = the queue the logits were computed with
+__global__ __launch_bounds__(256) void moco_logits_bwd_kernel(const float* __restrict__ q, const float* __restrict__ khat, const float* __restrict__ queue,
+                                                              const float* __restrict__ dlogits, float* __restrict__ dq, int B, int ED, int K, float invT) {
+    __shared__ float red[4];
+    const int l = blockIdx.x, b = blockIdx.y;
+    const float* qq = q + ((size_t)l * B + b) * ED; const float* kh = khat + ((size_t)l * B + b) * ED;
+    const float* dl = dlogits + ((size_t)l * B + b) * (1 + K);
+    const float* Q = queue + (size_t)l * ED * K;
+    float sq = 0.f;
+    for (int c = threadIdx.x; c < ED; c += 256) sq += qq[c] * qq[c];
+    sq = block_sum<256>(sq, red);
+    const float nq = fmaxf(sqrtf(sq), 1e-12f), iq = 1.f / nq;
+    // dqh[c] = (dl0 * kh[c] + sum_j dl[1+j] Q[c][j]) / T ;  dq = (dqh - qh (qh . dqh)) / |q|
+    float dot = 0.f;
+    float loc[4];                                   // ED <= 1024
+    for (int t = 0; t < 4; ++t) {
+        const int c = threadIdx.x + 256 * t;
+        loc[t] = 0.f;
+        if (c < ED) {
+            float s = dl[0] * kh[c];
+            for (int j = 0; j < K; ++j) s += dl[1 + j] * Q[(size_t)c * K + j];
+            loc[t] = s * invT;
+            dot += loc[t] * qq[c] * iq;
+        }
+    }
+    dot = block_sum<256>(dot, red);
+    for (int t = 0; t < 4; ++t) {
+        const int c = threadIdx.x + 256 * t;
+        if (c < ED) dq[((size_t)l * B + b) * ED + c] = (loc[t] - qq[c] * iq * dot) * iq;
+    }
+}
+// queue[l][c][ptr + b] = khat[l][b][c];  ptr = (ptr + B) % K   (moco.py:52-66)
+__global__ void moco_enqueue_kernel(float* __restrict__ queue, const float* __restrict__ khat, long long* __restrict__ ptr, int L, int B, int ED, int K) {
+    const int p = (int)*ptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L * B * ED; i += gridDim.x * blockDim.x) {
+        const int c = i % ED, b = (i / ED) % B, l = i / (ED * B);
+        queue[((size_t)l * ED + c) * K + p + b] = khat[i];
+    }
+}
+__global__ void moco_ptr_kernel(long long* __restrict__ ptr, int B, int K) { *ptr = (*ptr + B) % K; }
+
+// =====================================================================================================
+// LFS lambda heads
+// =====================================================================================================
+// xbar[i][b][c] = mean_t xhat[t][c], xhat = LayerNorm-normalised (no affine) rows of inter[i][b] ([64 tokens][C])
+__global__ __launch_bounds__(256) void lfs_xbar_kernel(const float* __restrict__ inter, float* __restrict__ xbar, float* __restrict__ stats, int NT, int C, float eps) {
+    __shared__ float mu[64], rs[64];
+    const size_t blk = (size_t)blockIdx.x;                 // (band, b) flattened
+    const float* x = inter + blk * NT * C;
+    const int w = threadIdx.x >> 6, l = lane_id();
+    for (int t = w; t < NT; t += 4) {
+        float s = 0.f;
+        for (int c = l; c < C; c += 64) s += x[(size_t)t * C + c];
+        const float m = wave_sum(s) / C;
+        float q = 0.f;
+        for (int c = l; c < C; c += 64) { const float d = x[(size_t)t * C + c] - m; q += d * d; }
+        const float r = rsqrtf(wave_sum(q) / C + eps);
+        if (l == 0) { mu[t] = m; rs[t] = r; stats[(blk * NT + t) * 2] = m; stats[(blk * NT + t) * 2 + 1] = r; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int t = 0; t < NT; ++t) s += (x[(size_t)t * C + c] - mu[t]) * rs[t];
+        xbar[blk * C + c] = s / NT;
+    }
+}
+// dinter[i][b][t][c] += LN-backward of dxhat[t][c] = dxbar[c] / NT
+__global__ __launch_bounds__(256) void lfs_xbar_bwd_kernel(const float* __restrict__ inter, const float* __restrict__ stats, const float* __restrict__ dxbar,
+                                                           float* __restrict__ dinter, int NT, int C) {
+    __shared__ float red[4];
+    const size_t blk = (size_t)blockIdx.x;
+    const float* x = inter + blk * NT * C; float* dx = dinter + blk * NT * C;
+    const float* g = dxbar + blk * C;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += g[c];
+    const float m1 = block_sum<256>(s, red) / C / NT;
+    const int w = threadIdx.x >> 6, l = lane_id();
+    for (int t = w; t < NT; t += 4) {
+        const float m = stats[(blk * NT + t) * 2], r = stats[(blk * NT + t) * 2 + 1];
+        float q = 0.f;
+        for (int c = l; c < C; c += 64) q += g[c] / NT * (x[(size_t)t * C + c] - m) * r;
+        const float m2 = wave_sum(q) / C;
+        for (int c = l; c < C; c += 64) {
+            const float xh = (x[(size_t)t * C + c] - m) * r;
+            dx[(size_t)t * C + c] += r * (g[c] / NT - m1 - xh * m2);
+        }
+    }
+}
+
+// pointer table per (block, band): 0 ln.w 1 ln.b 2 lin.w[h][C] 3 lin.b 4 mlp0.w[h][h] 5 mlp0.b 6 mlp2.w 7 mlp2.b
+// grid (nblk, B), 64 threads.  coef at coef + coef_off[blk] as [B][h][3].  save: [nblk][2][B][16][3] (u, a1, s)
+__global__ __launch_bounds__(64) void lfs_lambda_kernel(const float* __restrict__ xbar, const unsigned long long* __restrict__ ptab,
+                                                        const int* __restrict__ heads, const long long* __restrict__ coef_off,
+                                                        float* __restrict__ coef, float* __restrict__ save, int B, int C, int nb1) {
+    __shared__ float u[16], s1[16], lam[2][16];
+    const int blk = blockIdx.x, b = blockIdx.y, h = heads[blk], l = lane_id();
+    for (int band = 0; band < nb1; ++band) {
+        const unsigned long long* pt = ptab + ((size_t)blk * 2 + band) * 8;
+        const float* lnw = (const float*)pt[0]; const float* lnb = (const float*)pt[1];
+        const float* W = (const float*)pt[2]; const float* bl = (const float*)pt[3];
+        const float* W1 = (const float*)pt[4]; const float* b1 = (const float*)pt[5];
+        const float* W2 = (const float*)pt[6]; const float* b2 = (const float*)pt[7];
+        const float* xb = xbar + ((size_t)band * B + b) * C;
+        for (int hh = 0; hh < h; ++hh) {
+            float s = 0.f;
+            for (int c = l; c < C; c += 64) s += W[(size_t)hh * C + c] * (lnw[c] * xb[c] + lnb[c]);
+            s = wave_sum(s);
+            if (l == 0) u[hh] = s + bl[hh];
+        }
+        __syncthreads();
+        float* sv = save + ((((size_t)blk * 2 + band) * B + b) * 16) * 3;
+        if (l < h) {
+            float a = b1[l];
+            for (int j = 0; j < h; ++j) a += W1[l * h + j] * u[j];
+            s1[l] = lrelu_f(a, 0.1f);
+            sv[l * 3] = u[l]; sv[l * 3 + 1] = a; sv[l * 3 + 2] = s1[l];
+        }
+        __syncthreads();
+        if (l < h) {
+            float a = b2[l];
+            for (int j = 0; j < h; ++j) a += W2[l * h + j] * s1[j];
+            lam[band][l] = a;
+        }
+        __syncthreads();
+    }
+    if (l < h) {
+        float* cf = coef + coef_off[blk] + ((size_t)b * h + l) * 3;
+        if (nb1 == 2) { const float l1 = lam[0][l], l2 = lam[1][l]; cf[0] = 1.f + l2; cf[1] = -l2 * (1.f / 64.f); cf[2] = l1 - l2; }
+        else { const float l1 = lam[0][l]; cf[0] = 1.f + l1; cf[1] = -l1 * (1.f / 64.f); cf[2] = 0.f; }
+    }
+}
+// gtab: same layout as ptab but pointing at the gradient tensors (accumulated with atomics)
+__global__ __launch_bounds__(64) void lfs_lambda_bwd_kernel(const float* __restrict__ xbar, const unsigned long long* __restrict__ ptab,
+                                                            const unsigned long long* __restrict__ gtab, const int* __restrict__ heads,
+                                                            const long long* __restrict__ coef_off, const float* __restrict__ dcoef,
+                                                            const float* __restrict__ save, float* __restrict__ dxbar, int B, int C, int nb1) {
+    __shared__ float dl[16], da1[16], du[16];
+    const int blk = blockIdx.x, b = blockIdx.y, h = heads[blk], l = lane_id();
+    for (int band = 0; band < nb1; ++band) {
+        const unsigned long long* pt = ptab + ((size_t)blk * 2 + band) * 8;
+        const unsigned long long* gt = gtab + ((size_t)blk * 2 + band) * 8;
+        const float* lnw = (const float*)pt[0]; const float* lnb = (const float*)pt[1];
+        const float* W = (const float*)pt[2]; const float* W1 = (const float*)pt[4]; const float* W2 = (const float*)pt[6];
+        float* g_lnw = (float*)gt[0]; float* g_lnb = (float*)gt[1]; float* gW = (float*)gt[2]; float* gbl = (float*)gt[3];
+        float* gW1 = (float*)gt[4]; float* gb1 = (float*)gt[5]; float* gW2 = (float*)gt[6]; float* gb2 = (float*)gt[7];
+        const float* xb = xbar + ((size_t)band * B + b) * C;
+        const float* sv = save + ((((size_t)blk * 2 + band) * B + b) * 16) * 3;
+        if (l < h) {
+            const float* dc = dcoef + coef_off[blk] + ((size_t)b * h + l) * 3;
+            float d;
+            if (nb1 == 2) d = band == 0 ? dc[2] : (dc[0] - dc[1] * (1.f / 64.f) - dc[2]);
+            else d = dc[0] - dc[1] * (1.f / 64.f);
+            dl[l] = d;
+        }
+        __syncthreads();
+        if (l < h) {
+            atomicAdd(gb2 + l, dl[l]);
+            for (int j = 0; j < h; ++j) atomicAdd(gW2 + l * h + j, dl[l] * sv[j * 3 + 2]);
+            float ds = 0.f;
+            for (int j = 0; j < h; ++j) ds += W2[j * h + l] * dl[j];
+            da1[l] = sv[l * 3 + 1] > 0.f ? ds : ds * 0.1f;
+        }
+        __syncthreads();
+        if (l < h) {
+            atomicAdd(gb1 + l, da1[l]);
+            for (int j = 0; j < h; ++j) atomicAdd(gW1 + l * h + j, da1[l] * sv[j * 3]);
+            float d = 0.f;
+            for (int j = 0; j < h; ++j) d += W1[j * h + l] * da1[j];
+            du[l] = d;
+            atomicAdd(gbl + l, d);
+        }
+        __syncthreads();
+        for (int c = l; c < C; c += 64) {
+            const float z = lnw[c] * xb[c] + lnb[c];
+            float dz = 0.f;
+            for (int hh = 0; hh < h; ++hh) { atomicAdd(gW + (size_t)hh * C + c, du[hh] * z); dz += W[(size_t)hh * C + c] * du[hh]; }
+            atomicAdd(g_lnw + c, dz * xb[c]);
+            atomicAdd(g_lnb + c, dz);
+            atomicAdd(dxbar + ((size_t)band * B + b) * C + c, dz * lnw[c]);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+// spectrum scratch fr/fi: [nimg][N][N] f32 each.
+extern "C" int fw_dft2_fwd(const float* img, float* fr, float* fi, int nimg, int N, void* stream) {
+    FW_CHECK_ARG(img && fr && fi && nimg > 0 && N >= 8 && N <= 128 && (N & (N - 1)) == 0);
+    const size_t lds = (size_t)(2 * N * N + 2 * N) * 4;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dft2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); done = true; }
+    hipLaunchKernelGGL(dft2_fwd_kernel, dim3(nimg), dim3(256), lds, ST, img, fr, fi, N);
+    FW_LAUNCH_RET();
+}
+// mode 0: real band images (inverse=True) out [nb][nimg][N][N];  1: (re,im) pairs out [nb][nimg][N][N][2];  2: |.| fftshift-ed ('visual')
+extern "C" int fw_dft2_bands(const float* fr, const float* fi, const float* mask_unshifted, float* out, int nimg, int N, int nbands,
+                             int mode, void* stream) {
+    FW_CHECK_ARG(fr && fi && mask_unshifted && out && nimg > 0 && N >= 8 && N <= 128 && (N & (N - 1)) == 0 && nbands > 0 && mode >= 0 && mode <= 2);
+    if (mode == 0) {
+        const size_t lds = (size_t)(2 * N * N + 2 * N) * 4;
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dft2_band_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); done = true; }
+        hipLaunchKernelGGL(dft2_band_inv_kernel, dim3(nimg, nbands), dim3(256), lds, ST, fr, fi, mask_unshifted, out, N, nimg);
+    } else {
+        hipLaunchKernelGGL(dft2_band_spec_kernel, dim3(nimg, nbands), dim3(256), 0, ST, fr, fi, mask_unshifted, out, N, nimg, mode - 1);
+    }
+    FW_LAUNCH_RET();
+}
+extern "C" int fw_dc_split(const float* img, float* out, int nimg, int NN, void* stream) {
+    FW_CHECK_ARG(img && out && nimg > 0 && NN > 0);
+    hipLaunchKernelGGL(dc_split_kernel, dim3(nimg), dim3(256), 0, ST, img, out, NN, nimg);
+    FW_LAUNCH_RET();
+}
+
+// fea: T [B][ED][P] (the 448 -> ED*256 Linear output viewed per sample).  part: f32 [ED][B][2] scratch.  saved: f32 [ED][2].
+extern "C" int fw_bn_lrelu_gap_fwd(int dtype, const void* fea, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                   long long* nbt, float* part, float* saved, float* gap, int B, int ED, int P, int training,
+                                   float eps, float momentum, float slope, void* stream) {
+    FW_CHECK_ARG(fea && gamma && beta && rmean && rvar && gap && B > 0 && ED > 0 && P > 0 && (!training || (part && saved && nbt)));
+    if (dtype == FW_DT_BF16) {
+        if (training) hipLaunchKernelGGL((bn_stats_kernel<bf16raw>), dim3(ED, B), dim3(256), 0, ST, (const bf16raw*)fea, part, B, ED, P);
+        hipLaunchKernelGGL((bn_apply_gap_kernel<bf16raw>), dim3(ED, B), dim3(256), 0, ST, (const bf16raw*)fea, part, gamma, beta, rmean, rvar, nbt,
+                           gap, saved, B, ED, P, training, eps, momentum, slope);
+    } else {
+        if (training) hipLaunchKernelGGL((bn_stats_kernel<float>), dim3(ED, B), dim3(256), 0, ST, (const float*)fea, part, B, ED, P);
+        hipLaunchKernelGGL((bn_apply_gap_kernel<float>), dim3(ED, B), dim3(256), 0, ST, (const float*)fea, part, gamma, beta, rmean, rvar, nbt, gap,
+                           saved, B, ED, P, training, eps, momentum, slope);
+    }
+    FW_LAUNCH_RET();
+}
+extern "C" int fw_bn_lrelu_gap_bwd(int dtype, const void* fea, const float* gamma, const float* beta, const float* saved, const float* dgap,
+                                   float* part2, void* dfea, float* dgamma, float* dbeta, int B, int ED, int P, float slope, void* stream) {
+    FW_CHECK_ARG(fea && gamma && beta && saved && dgap && part2 && dfea && dgamma && dbeta);
+    if (dtype == FW_DT_BF16) {
+        hipLaunchKernelGGL((bn_bwd_stats_kernel<bf16raw>), dim3(ED, B), dim3(256), 0, ST, (const bf16raw*)fea, saved, gamma, beta, dgap, part2, B, ED, P, slope);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16raw>), dim3(ED, B), dim3(256), 0, ST, (const bf16raw*)fea, saved, gamma, beta, dgap, part2,
+                           (bf16raw*)dfea, dgamma, dbeta, B, ED, P, slope);
+    } else {
+        hipLaunchKernelGGL((bn_bwd_stats_kernel<float>), dim3(ED, B), dim3(256), 0, ST, (const float*)fea, saved, gamma, beta, dgap, part2, B, ED, P, slope);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(ED, B), dim3(256), 0, ST, (const float*)fea, saved, gamma, beta, dgap, part2, (float*)dfea,
+                           dgamma, dbeta, B, ED, P, slope);
+    }
+    FW_LAUNCH_RET();
+}
+
+extern "C" int fw_moco_logits(const float* q, const float* k, const float* queue, float* logits, float* khat, int L, int B, int ED, int K,
+                              float invT, void* stream) {
+    FW_CHECK_ARG(q && k && queue && logits && khat && L > 0 && B > 0 && ED > 0 && ED <= 1024 && K > 0);
+    hipLaunchKernelGGL(moco_logits_kernel, dim3(L, B), dim3(256), (size_t)ED * 4, ST, q, k, queue, logits, khat, B, ED, K, invT);
+    FW_LAUNCH_RET();
+}
+extern "C" int fw_moco_logits_bwd(const float* q, const float* khat, const float* queue, const float* dlogits, float* dq, int L, int B, int ED,
+                                  int K, float invT, void* stream) {
+    FW_CHECK_ARG(q && khat && queue && dlogits && dq && ED <= 1024);
+    hipLaunchKernelGGL(moco_logits_bwd_kernel, dim3(L, B), dim3(256), 0, ST, q, khat, queue, dlogits, dq, B, ED, K, invT);
+    FW_LAUNCH_RET();
+}
+extern "C" int fw_moco_enqueue(float* queue, const float* khat, long long* ptr, int L, int B, int ED, int K, void* stream) {
+    FW_CHECK_ARG(queue && khat && ptr && K % B == 0);
+    hipLaunchKernelGGL(moco_enqueue_kernel, dim3(fw_cdiv((long)L * B * ED, 256)), dim3(256), 0, ST, queue, khat, ptr, L, B, ED, K);
+    hipLaunchKernelGGL(moco_ptr_kernel, dim3(1), dim3(1), 0, ST, ptr, B, K);
+    FW_LAUNCH_RET();
+}
+
+// inter: f32 [nb1*B][NT][C] (bands 1.. of the encoder output, contiguous).  stats: f32 [nb1*B][NT][2].
+extern "C" int fw_lfs_xbar(const float* inter, float* xbar, float* stats, int nb1, int B, int NT, int C, float eps, void* stream) {
+    FW_CHECK_ARG(inter && xbar && stats && NT <= 64 && NT > 0);
+    hipLaunchKernelGGL(lfs_xbar_kernel, dim3(nb1 * B), dim3(256), 0, ST, inter, xbar, stats, NT, C, eps);
+    FW_LAUNCH_RET();
+}
+extern "C" int fw_lfs_xbar_bwd(const float* inter, const float* stats, const float* dxbar, float* dinter, int nb1, int B, int NT, int C, void* stream) {
+    FW_CHECK_ARG(inter && stats && dxbar && dinter);
+    hipLaunchKernelGGL(lfs_xbar_bwd_kernel, dim3(nb1 * B), dim3(256), 0, ST, inter, stats, dxbar, dinter, NT, C);
+    FW_LAUNCH_RET();
+}
+extern "C" int fw_lfs_lambda(const float* xbar, const unsigned long long* ptab, const int* heads, const long long* coef_off, float* coef,
+                             float* save, int nblk, int B, int C, int nb1, void* stream) {
+    FW_CHECK_ARG(xbar && ptab && heads && coef_off && coef && save && nblk > 0 && (nb1 == 1 || nb1 == 2));
+    hipLaunchKernelGGL(lfs_lambda_kernel, dim3(nblk, B), dim3(64), 0, ST, xbar, ptab, heads, coef_off, coef, save, B, C, nb1);
+    FW_LAUNCH_RET();
+}
+extern "C" int fw_lfs_lambda_bwd(const float* xbar, const unsigned long long* ptab, const unsigned long long* gtab, const int* heads,
+                                 const long long* coef_off, const float* dcoef, const float* save, float* dxbar, int nblk, int B, int C,
+                                 int nb1, void* stream) {
+    FW_CHECK_ARG(xbar && ptab && gtab && heads && coef_off && dcoef && save && dxbar && (nb1 == 1 || nb1 == 2));
+    hipLaunchKernelGGL(lfs_lambda_bwd_kernel, dim3(nblk, B), dim3(64), 0, ST, xbar, ptab, gtab, heads, coef_off, dcoef, save, dxbar, B, C, nb1);
+    FW_LAUNCH_RET();
+}

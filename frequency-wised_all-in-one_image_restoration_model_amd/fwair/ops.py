@@ -1,0 +1,160 @@
+"""Tensor-level wrappers over the C ABI (include/fwair.h).  They only allocate outputs with the PyTorch
+caching allocator, check shapes on the host and forward raw pointers; all arithmetic happens in
+libfwair_hip.so.  Activations are 2-D [tokens, channels] tensors whose row stride is their `ld`."""
+import torch
+
+from . import lfs as _lfs
+from .lib import call, dt
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, 'expect a row-major 2-D view'
+    return t.stride(0)
+
+
+def empty(rows, cols, dtype, device):
+    return torch.empty((rows, cols), dtype=dtype, device=device)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(x, w, M, N, K, *, x_trans=False, w_trans=False, x_op=0, w_op=0, out=None, out_dtype=None, bias=None,
+         act=0, slope=0.0, aux=None, rowscale=None, rows_per_scale=1, residual=None, accumulate=False, splitk=1,
+         alpha=1.0):
+    """C[M,N] = epi(alpha * X W^T).  x: [M,K] (or [K,M] when x_trans), w: [N,K] (or [K,N] when w_trans)."""
+    assert x.dtype == w.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or x.dtype, device=x.device)
+    out_f32 = int(out.dtype == torch.float32)
+    call('fw_gemm', dt(x.dtype), x, _ld(x), int(x_trans), x_op, w, _ld(w), int(w_trans), w_op, out, _ld(out), out_f32,
+         int(accumulate), M, N, K, float(alpha), bias, act, float(slope), aux, _ld(aux) if aux is not None else 0,
+         rowscale, rows_per_scale, residual, _ld(residual) if residual is not None else 0, splitk)
+    return out
+
+
+def pick_splitk(M, N, K, dtype):
+    """Split the reduction so that a weight-gradient GEMM (small M x N, huge K) fills the chip."""
+    kt = 64 if dtype == torch.bfloat16 else 32
+    tiles = ((M + 127) // 128) * ((N + (63 if N <= 64 else 127)) // (64 if N <= 64 else 128))
+    steps = (K + kt - 1) // kt
+    want = max(1, 1024 // tiles)
+    return int(max(1, min(want, steps // 4 if steps >= 8 else 1)))
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
+    rows, C = x.shape
+    y = torch.empty((rows, C), dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call('fw_layernorm_fwd', dt(out_dtype), x, _ld(x), gamma, beta, y, _ld(y), mean, rstd, rows, C, eps)
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
+    rows, C = x.shape
+    dx = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    call('fw_layernorm_bwd', dt(dy.dtype), dy, _ld(dy), x, _ld(x), gamma, mean, rstd, dres,
+         _ld(dres) if dres is not None else 0, dx, _ld(dx), dgamma, dbeta, rows, C)
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_fwd(qkv, C, B, H, W, heads, L, mode, shift, bias, coef=None, lfs=0):
+    """qkv: [L*B*H*W, 3C] (q | k | v).  bias: f32 [L*L or 1, 225, heads].  -> out [rows, C], lse."""
+    rows = qkv.shape[0]
+    D = C // heads
+    nkt = 1 if mode == 0 else L - 1
+    out = torch.empty((rows, C), dtype=qkv.dtype, device=qkv.device)
+    nitems = B * (H // 8) * (W // 8) * L * heads
+    lse = torch.empty((nitems, 64), dtype=torch.float32, device=qkv.device)
+    tab = _lfs.device_table(qkv.dtype, qkv.device) if lfs == 2 else None
+    call('fw_attn_fwd', dt(qkv.dtype), D, nkt, lfs, qkv, qkv[:, C:], qkv[:, 2 * C:], _ld(qkv), out, _ld(out), lse, bias,
+         coef, tab, B, H, W, heads, L, mode, shift, float(D) ** -0.5)
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, C, B, H, W, heads, L, mode, shift, bias, dbias_dense, coef=None, dcoef=None, lfs=0):
+    """-> dqkv [rows, 3C].  dbias_dense f32 [ntab, heads, 64, 64] and dcoef are accumulated into."""
+    rows = qkv.shape[0]
+    D = C // heads
+    nkt = 1 if mode == 0 else L - 1
+    dqkv = torch.empty_like(qkv)
+    d2 = torch.empty_like(qkv) if nkt == 2 else None          # second key-gradient slot, same layout as dqkv
+    tab = _lfs.device_table(qkv.dtype, qkv.device) if lfs == 2 else None
+    call('fw_attn_bwd', dt(qkv.dtype), D, nkt, lfs, qkv, qkv[:, C:], qkv[:, 2 * C:], _ld(qkv), out, _ld(out), dout, _ld(dout),
+         lse, bias, coef, tab, dqkv, dqkv[:, C:], dqkv[:, 2 * C:], d2[:, C:] if d2 is not None else None,
+         d2[:, 2 * C:] if d2 is not None else None, _ld(dqkv),
+         dbias_dense, dcoef, B, H, W, heads, L, mode, shift, float(D) ** -0.5)
+    if nkt == 2:
+        call('fw_add_rows', dt(qkv.dtype), d2[:, C:], _ld(d2), dqkv[:, C:], _ld(dqkv), rows, 2 * C)
+    return dqkv
+
+
+def rel_index(device):
+    """[64*64] int64 index into the 225-entry table (decoder_Uformer.py:201-210), host-built constant."""
+    ch = torch.arange(8)
+    coords = torch.stack(torch.meshgrid([ch, ch], indexing='ij')).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += 7
+    rel[:, :, 1] += 7
+    rel[:, :, 0] *= 15
+    return rel.sum(-1).to(device)
+
+
+# ------------------------------------------------------------------------------------------------ LeFF dwconv
+def dwconv_fwd(h1, w, bias, B, H, W):
+    h2 = torch.empty_like(h1)
+    call('fw_dwconv_fwd', dt(h1.dtype), h1, _ld(h1), w, bias, h2, _ld(h2), B, H, W, h1.shape[1])
+    return h2
+
+
+def dwconv_bwd(dh2, h1, w, dw, dbias, B, H, W):
+    dh1 = torch.empty_like(h1)
+    call('fw_dwconv_bwd', dt(h1.dtype), dh2, _ld(dh2), h1, _ld(h1), w, dh1, _ld(dh1), dw, dbias, B, H, W, h1.shape[1])
+    return dh1
+
+
+# ------------------------------------------------------------------------------------------------ convs
+def im2col4(x, B, H, W, dtype):
+    C = x.shape[1]
+    col = torch.empty((B * (H // 2) * (W // 2), 16 * C), dtype=dtype, device=x.device)
+    call('fw_im2col4', dt(dtype), x, _ld(x), col, B, H, W, C)
+    return col
+
+
+def col2im4(dcol, B, H, W, C, dres=None):
+    dx = torch.empty((B * H * W, C), dtype=torch.float32, device=dcol.device)
+    call('fw_col2im4', dt(dcol.dtype), dcol, dx, _ld(dx), dres, _ld(dres) if dres is not None else 0, B, H, W, C)
+    return dx
+
+
+def pixel_shuffle(g, bias, out, B, H, W, Cout):
+    call('fw_pixel_shuffle', dt(g.dtype), g, bias, out, _ld(out), B, H, W, Cout)
+    return out
+
+
+def pixel_unshuffle(dout, B, H, W, Cout, dtype):
+    dg = torch.empty((B * H * W, 4 * Cout), dtype=dtype, device=dout.device)
+    call('fw_pixel_unshuffle', dt(dtype), dout, _ld(dout), dg, B, H, W, Cout)
+    return dg
+
+
+def colsum(x, out):
+    call('fw_colsum', 1 if x.dtype == torch.bfloat16 else 0, x, _ld(x), out, x.shape[0], x.shape[1])
+
+
+def cast_rows(src, dtype, rowscale=None, rows_per_scale=1):
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    call('fw_cast_rows', dt(dtype), src, _ld(src), dst, _ld(dst), src.shape[0], src.shape[1], rowscale, rows_per_scale)
+    return dst
+
+
+def copy_rows(src, dst, accumulate=False):
+    call('fw_copy_rows', src, _ld(src), dst, _ld(dst), src.shape[0], src.shape[1], int(accumulate))
+
+
+def permute3(src, dst, dims, out_strides, accumulate=False):
+    ind = 1 if src.dtype == torch.bfloat16 else 0
+    outd = 1 if dst.dtype == torch.bfloat16 else 0
+    call('fw_permute3', ind, outd, src, dst, dims[0], dims[1], dims[2], out_strides[0], out_strides[1], out_strides[2],
+         int(accumulate))

@@ -1,0 +1,148 @@
+/* fwair.h -- C ABI of libfwair_hip.so: the MI355X (gfx950) kernels behind the AirNet training hot path.
+ *
+ * The reference (stcodeer/Frequency-wised_All-in-One_Image_Restoration_Model) is pure eager PyTorch; it
+ * has no native ABI.  Each entry point below replaces the PyTorch operator sequence cited next to it
+ * (file:line relative to the reference root).  The Python host (net/model.py ... in the package
+ * directory) binds these through ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every device buffer is owned by the caller (PyTorch allocator);
+ *     the library never allocates, frees or retains device memory and never synchronises the device;
+ *   - `dtype`: 0 = f32, 1 = bf16 ("T" below) -- the storage type of activations / GEMM operands;
+ *     accumulation, the residual stream, statistics, losses, parameters and gradients are f32;
+ *   - leading dimensions (`ld*`) are in ELEMENTS; rows are tokens (b, y, x) in raster order;
+ *   - `stream` is a hipStream_t; every function is re-entrant and takes its stream per call;
+ *   - return value: 0 ok, < 0 argument / shape error (the negated source line), > 0 a hipError_t.
+ */
+#ifndef FWAIR_H
+#define FWAIR_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- GEMM: C[m][n] = epi(alpha * sum_k X(m,k) W(n,k)) ------------------------------------------------
+ * nn.Linear forward/backward: net/decoder_Uformer.py:98-125 (to_q/to_kv), :294 (proj),
+ * net/utils/leff.py:100,114 (linear1/linear2), net/encoder_Uformer.py:942,954-956 (heads); with
+ * fw_im2col4 / fw_pixel_shuffle also Conv2d k4s2p1 and ConvTranspose2d k2s2 (decoder_Uformer.py:414-449).
+ * x_trans / w_trans = 1: the operand is stored reduction-major (element (i,k) at k*ld + i).
+ * x_op / w_op = 1: GELU applied to the operand while it is staged (leff.py:100,106 activations).
+ * act: 0 none, 1 LeakyReLU(slope), 2 multiply by GELU'(aux[m][n]), 3 GELU.
+ * epilogue order: alpha, +bias[n], act, *rowscale[m / rows_per_scale] (DropPath), +residual[m][n] (f32).
+ * out_f32: C is f32 (else T).  accumulate: atomicAdd into f32 C (required when splitk > 1). */
+int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op, const void* W, long ldw, int w_trans, int w_op,
+            void* C, long ldc, int out_f32, int accumulate, int M, int N, int K, float alpha, const float* bias, int act,
+            float slope, const void* aux, long ldaux, const float* rowscale, int rows_per_scale, const float* residual,
+            long ldr, int splitk, void* stream);
+
+/* ---- LayerNorm over the f32 stream -> T (decoder_Uformer.py:567,594,666,744; encoder_Uformer.py:941) -- */
+int fw_layernorm_fwd(int dtype, const float* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                     float* mean, float* rstd, int rows, int C, float eps, void* stream);
+/* dx = (dres?) + LN'(dy); dgamma, dbeta accumulated */
+int fw_layernorm_bwd(int dtype, const void* dy, long lddy, const float* x, long ldx, const float* gamma, const float* mean,
+                     const float* rstd, const float* dres, long lddres, float* dx, long lddx, float* dgamma, float* dbeta,
+                     int rows, int C, void* stream);
+
+/* ---- window attention (decoder_Uformer.py:240-293 with :387-409,634-651,678-686,721-729 folded in;
+ *      encoder_Uformer.py:152-183 "origin", :256-310 intra / inter band attention) ---------------------
+ * q/k/v: T rows = tokens of B*L images of H x W, head h at column h*D; D in {56, 28}.
+ * L: bands (1 for the decoder); mode 0: keys = the query's own band, 1: keys = the other L-1 bands (nkt = L-1).
+ * bias: f32 [L*L][225][heads] relative-position tables; shift: cyclic shift (0 or 4).
+ * lfs: 0 none; 1 P' = a P + b; 2 P' = a P + b + c B1(P) with coef f32 [B][heads][3] = (a,b,c) and lfs_tab the
+ * DFT panels of fw_attn_lfs_table_elems() T elements followed by the f32 mask [48][32] (host: fwair/lfs.py).
+ * lse: f32 [B*nW*L*heads][64] log-sum-exp saved for the backward pass. */
+int fw_attn_lfs_table_elems(void);
+int fw_attn_fwd(int dtype, int D, int nkt, int lfs, const void* q, const void* k, const void* v, long ld, void* out, long ldo,
+                float* lse, const float* bias, const float* coef, const void* lfs_tab, int B, int H, int W, int heads, int L,
+                int mode, int shift, float scale, void* stream);
+/* dbias: f32 [L*L][225][heads] (layout of `bias`); dcoef: f32 [B][heads][3]; both accumulated.  dk2/dv2: second slot of
+ * key gradients when nkt == 2 (each key band is attended by two query bands). */
+int fw_attn_bwd(int dtype, int D, int nkt, int lfs, const void* q, const void* k, const void* v, long ld, const void* out,
+                long ldo, const void* dout, long lddo, const float* lse, const float* bias, const float* coef,
+                const void* lfs_tab, void* dq, void* dk, void* dv, void* dk2, void* dv2, long ldd, float* dbias,
+                float* dcoef, int B, int H, int W, int heads, int L, int mode, int shift, float scale, void* stream);
+
+/* ---- LeFF depthwise 3x3 (net/utils/leff.py:104-111): h2 = dwconv(GELU(h1)) + bias; w f32 [C][9] ------ */
+int fw_dwconv_fwd(int dtype, const void* h1, long ld1, const float* w, const float* bias, void* h2, long ld2, int B, int H,
+                  int W, int C, void* stream);
+int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* h1, long ld1, const float* w, void* dh1, long ldo,
+                  float* dw, float* dbias, int B, int H, int W, int C, void* stream);
+
+/* ---- Downsample conv k4 s2 p1 (decoder_Uformer.py:414-430) as GEMM: K order (ky, kx, ci) -------------- */
+int fw_im2col4(int dtype, const float* x, long ldx, void* col, int B, int H, int W, int C, void* stream);
+int fw_col2im4(int dtype, const void* dcol, float* dx, long lddx, const float* dres, long ldr, int B, int H, int W, int C,
+               void* stream);
+/* ---- Upsample convT k2 s2 (decoder_Uformer.py:434-449) = Linear(Cin -> 4 Cout) + depth-to-space ------- */
+int fw_pixel_shuffle(int dtype, const void* g, const float* bias, float* out, long ldo, int B, int H, int W, int Cout,
+                     void* stream);
+int fw_pixel_unshuffle(int dtype, const float* dout, long ldo, void* dg, int B, int H, int W, int Cout, void* stream);
+int fw_colsum(int x_dtype, const void* x, long ldx, float* out, long rows, int cols, void* stream);
+
+/* ---- InputProj 3x3 conv 3->C + LeakyReLU(0.01) (decoder_Uformer.py:453-472), NCHW f32 image ----------- */
+int fw_inproj_fwd(const float* img, const float* w, const float* bias, float* out, long ldo, int B, int H, int W, int C,
+                  float slope, void* stream);
+int fw_inproj_bwd(const float* img, const float* out, long ldo, const float* dy, long ldy, float* dw, float* db, int B, int H,
+                  int W, int C, float slope, void* stream);
+/* ---- OutputProj 3x3 conv C->3 + global residual x + y (decoder_Uformer.py:476-499,1171) --------------- */
+int fw_outproj_fwd(const float* fea, long ldf, const float* w, const float* bias, const float* img, float* out, int B, int H,
+                   int W, int C, void* stream);
+int fw_outproj_bwd(const float* dout, const float* fea, long ldf, const float* w, float* dfea, long lddf, float* dw, float* db,
+                   int B, int H, int W, int C, void* stream);
+
+/* ---- casts / copies / re-layouts ------------------------------------------------------------------ */
+int fw_cast_rows(int dtype, const float* src, long lds_, void* dst, long ldd, long rows, int cols, const float* rowscale,
+                 int rows_per_scale, void* stream);
+int fw_copy_rows(const float* src, long lds_, float* dst, long ldd, long rows, int cols, int accumulate, void* stream);
+int fw_add_rows(int dtype, const void* src, long lds_, void* dst, long ldd, long rows, int cols, void* stream);
+int fw_cast_flat(int dtype, const float* src, void* dst, long n, void* stream);
+int fw_permute3(int in_dtype, int out_dtype, const void* in, void* out, int d0, int d1, int d2, long s0, long s1, long s2,
+                int accumulate, void* stream);
+int fw_fill(float* p, long n, float v, void* stream);
+/* LeakyReLU on a contiguous f32 vector -> T, and its backward (encoder_Uformer.py:953-957 head MLPs) */
+int fw_lrelu_fwd(int dtype, const float* x, void* y, long n, float slope, void* stream);
+int fw_lrelu_bwd(int dtype, const void* dy, const float* x, float* dx, long n, float slope, void* stream);
+
+/* ---- losses (train.py:88-92): loss accumulated into *loss; gradient scaled by gscale ----------------- */
+int fw_l1_loss(const float* a, const float* b, float* da, long n, float gscale, float* loss, void* stream);
+int fw_ce0_loss(const float* logits, float* dlogits, int R, int N, float gscale, float* loss, void* stream);
+
+/* ---- Adam (train.py:63,96; torch.optim.Adam defaults) and MoCo EMA (net/utils/moco.py:44-50) ----------
+ * hyper: device f32[4] = {lr, beta1^t, beta2^t, 0}; fw_adam_tick advances t so graphs replay correctly. */
+int fw_adam_tick(float* hyper, float b1, float b2, void* stream);
+int fw_adam(int shadow_dtype, float* p, const float* g, float* m, float* v, void* shadow, long n, const float* hyper, float b1,
+            float b2, float eps, void* stream);
+int fw_ema(int shadow_dtype, float* pk, const float* pq, void* shadow, long n, float momentum, void* stream);
+
+/* ---- image band decomposition (net/utils/frequency_decompose.py:28-118) ------------------------------ */
+int fw_dft2_fwd(const float* img, float* fr, float* fi, int nimg, int N, void* stream);
+int fw_dft2_bands(const float* fr, const float* fi, const float* mask_unshifted, float* out, int nimg, int N, int nbands,
+                  int mode, void* stream);
+int fw_dc_split(const float* img, float* out, int nimg, int NN, void* stream);
+
+/* ---- encoder contrastive head: BatchNorm2d + LeakyReLU(0.1) + GAP (encoder_Uformer.py:945-951,978-984) -- */
+int fw_bn_lrelu_gap_fwd(int dtype, const void* fea, const float* gamma, const float* beta, float* rmean, float* rvar,
+                        long long* nbt, float* part, float* saved, float* gap, int B, int ED, int P, int training, float eps,
+                        float momentum, float slope, void* stream);
+int fw_bn_lrelu_gap_bwd(int dtype, const void* fea, const float* gamma, const float* beta, const float* saved, const float* dgap,
+                        float* part2, void* dfea, float* dgamma, float* dbeta, int B, int ED, int P, float slope, void* stream);
+
+/* ---- MoCo logits / enqueue (net/utils/moco.py:127-164, 52-66) ---------------------------------------- */
+int fw_moco_logits(const float* q, const float* k, const float* queue, float* logits, float* khat, int L, int B, int ED, int K,
+                   float invT, void* stream);
+int fw_moco_logits_bwd(const float* q, const float* khat, const float* queue, const float* dlogits, float* dq, int L, int B,
+                       int ED, int K, float invT, void* stream);
+int fw_moco_enqueue(float* queue, const float* khat, long long* ptr, int L, int B, int ED, int K, void* stream);
+
+/* ---- learned-frequency-selection lambda heads of all decoder blocks (decoder_Uformer.py:178-193,279-284) -- */
+int fw_lfs_xbar(const float* inter, float* xbar, float* stats, int nb1, int B, int NT, int C, float eps, void* stream);
+int fw_lfs_xbar_bwd(const float* inter, const float* stats, const float* dxbar, float* dinter, int nb1, int B, int NT, int C,
+                    void* stream);
+int fw_lfs_lambda(const float* xbar, const unsigned long long* ptab, const int* heads, const long long* coef_off, float* coef,
+                  float* save, int nblk, int B, int C, int nb1, void* stream);
+int fw_lfs_lambda_bwd(const float* xbar, const unsigned long long* ptab, const unsigned long long* gtab, const int* heads,
+                      const long long* coef_off, const float* dcoef, const float* save, float* dxbar, int nblk, int B, int C,
+                      int nb1, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

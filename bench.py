@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- training images/sec of the AirNet hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|fp32] [--no-graph] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one phase-2 training step of train.py:80-96 on one synthetic batch: zero grads, AirNet forward
+(query encoder, key-encoder EMA + forward, MoCo logits, decoder with learned frequency selection), L1 + 0.6 * CE,
+backward, (gradient all-reduce over RCCL), Adam.  Workload = BASELINE.json configs[1]: Uformer encoder + decoder,
+denoise sigma = 25, 128x128, batch 16 per GPU, bf16 operands / f32 accumulation.  Weak scaling (fixed per-GPU batch).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'frequency-wised_all-in-one_image_restoration_model_amd')
+sys.path.insert(0, PKG)
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+FLOP_PER_IMAGE_STEP = 554.9e9        # 3*(34.72+138.66)+34.72 GFLOP, dense contractions only
+PEAK_BF16 = 2.5e15                   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_MFMA = 157.3e12
+PEAK_HBM = 8.0e12
+
+
+def synth_batch(B, size, sigma, seed, device):
+    """low-frequency cosines + rectangles, uint8-quantised; noise as utils/dataset_utils.py:126."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    clean = np.zeros((B, 3, size, size), np.float32)
+    for b in range(B):
+        for c in range(3):
+            img = np.zeros((size, size), np.float32)
+            for _ in range(8):
+                fx, fy, ph, a = rs.uniform(0, 4), rs.uniform(0, 4), rs.uniform(0, 6.28), rs.uniform(0.2, 1)
+                img += a * np.cos(6.2832 * (fx * xx + fy * yy) + ph)
+            for _ in range(4):
+                x0, y0 = rs.randint(0, size - 8, 2)
+                w, h = rs.randint(8, size // 2, 2)
+                img[y0:y0 + h, x0:x0 + w] += rs.uniform(-1, 1)
+            img = (img - img.min()) / max(img.max() - img.min(), 1e-6)
+            clean[b, c] = np.round(img * 255) / 255
+    def noisy():
+        return np.clip(clean * 255 + sigma * rs.randn(*clean.shape), 0, 255).astype(np.uint8).astype(np.float32) / 255
+    t = lambda a: torch.from_numpy(a).to(device)
+    return t(clean), t(noisy()), t(noisy())
+
+
+def make_opt(batch, dtype):
+    import types
+    return types.SimpleNamespace(L=3, encoder_dim=256, encoder_embed_dim=28, embed_dim=56, batch_size=batch, patch_size=128,
+                                 degradation_embedding_method=['all_3_bands'], encoder_msa_type='freq', contrast_loss_weight=0.6,
+                                 encoder_type='Uformer', decoder_type='Uformer', debug_mode=False, frequency_decompose_type='none',
+                                 learnable_modulator=False, compute_dtype=dtype, de_type=['denoising_25'] * batch)
+
+
+def gemm_profile(engine, batch, steps=2):
+    """HIP-event timing of every fw_gemm launch of `steps` eager training steps, on the stream the kernels run on."""
+    from fwair import lib, ops
+    rec = []
+    orig = ops.gemm
+
+    def timed(x, w, M, N, K, **kw):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = orig(x, w, M, N, K, **kw)
+        b.record()
+        variant = ('bf16' if x.dtype == torch.bfloat16 else 'f32', 64 if N <= 64 else 128, bool(kw.get('x_trans')), bool(kw.get('w_trans')))
+        rec.append((variant, 2.0 * M * N * K, a, b))
+        return r
+
+    ops.gemm = timed
+    try:
+        for _ in range(steps):
+            engine.step_eager(*batch)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm = orig
+    agg = {}
+    for variant, fl, a, b in rec:
+        d = agg.setdefault(variant, [0.0, 0.0, 0])
+        d[0] += fl; d[1] += a.elapsed_time(b) * 1e-3; d[2] += 1
+    return agg, len(rec) // steps
+
+
+def cpu_baseline(threads):
+    """The CPU oracle (oracle/airnet_oracle.py, the fp32 restatement pinned against the reference) timed on the host
+    cores: phase-2 steps (forward + backward + Adam) at B = 2, 128x128 -- a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import airnet_oracle as O
+    from helpers import schema
+    torch.set_num_threads(threads)
+    B = 2
+    opt = O.make_opt(batch_size=B)
+    st = O.fill_state_seeded(schema('all3'))
+    names = [k for k in st if st[k] is not None and st[k].is_floating_point() and O.is_parameter_key(k) and not k.startswith('E.E.encoder_k.')]
+    for n in names:
+        st[n] = st[n].clone().requires_grad_(True)
+    optim = torch.optim.Adam([st[n] for n in names], lr=2e-4)
+    clean, q, k = (t.cpu() for t in synth_batch(B, 128, 25, 99, 'cpu'))
+    t0 = time.time()
+    steps = 0
+    while steps < 2:
+        optim.zero_grad()
+        restored, logits, labels = O.airnet_forward(st, opt, q, k, True)
+        loss, _, _ = O.training_loss(opt, restored, logits, labels, clean)
+        loss.backward()
+        optim.step()
+        steps += 1
+        if steps == 1:
+            t0 = time.time()           # first step = warm-up (allocator, thread pools)
+    dt = time.time() - t0
+    return {'value': round(B * (steps - 1) / dt, 4), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'{steps - 1} phase-2 train step(s) (fwd+bwd+Adam) of the CPU oracle, B={B}, 128x128, fp32, after 1 warm-up step'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    args = ap.parse_args()
+
+    from fwair import engine as E
+    rank, local, world = E.init_distributed()
+    assert world == max(1, args.gpus) or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    from net.model import AirNet
+    torch.manual_seed(1234)
+    opt = make_opt(args.batch, args.dtype)
+    net = AirNet(opt).to(dev).train()
+    eng = E.TrainEngine(net, lr=2e-4, contrast_loss_weight=0.6, use_graph=not args.no_graph)
+    batch = synth_batch(args.batch, 128, 25, 1234 + rank, dev)
+    clean, xq, xk = batch
+    data = (xq, xk, clean)
+
+    graph_ok = not args.no_graph
+    try:
+        for _ in range(max(1, args.warmup)):
+            out = eng.step(*data)
+    except Exception as e:                                   # capture problems must not cost the measurement
+        if args.no_graph:
+            raise
+        print(f'[bench] graph capture failed ({type(e).__name__}: {e}); falling back to eager launches', file=sys.stderr)
+        graph_ok = False
+        eng.use_graph = False
+        for _ in range(max(1, args.warmup)):
+            out = eng.step(*data)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.step(*data)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    loss = [float(v) for v in out]
+    ips = args.batch * world * args.steps / dt
+
+    res = {
+        'metric': 'training images/sec @128x128', 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: Uformer encoder+decoder (all_3_bands, L=3, freq MSA), denoise sigma=25, '
+                               '128x128, phase-2 train step (fwd+bwd+Adam, DropPath on)', 'per_gpu_batch': args.batch,
+                   'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'hip_graph': graph_ok},
+        'loss': {'total': loss[0], 'l1': loss[1], 'contrast': loss[2]},
+    }
+    peak = PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32_MFMA
+    res['step_mfma_fraction'] = round(ips / world * FLOP_PER_IMAGE_STEP / peak, 5)
+    if rank == 0 and world == 1 and not args.no_profile:
+        agg, launches = gemm_profile(eng, data)
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        tot_t = sum(v[1] for v in agg.values())
+        v, (fl, tt, cnt) = dom
+        res['roofline'] = {'bound': 'mfma', 'kernel': f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>',
+                           'achieved': round(fl / tt / 1e12, 2), 'peak': peak / 1e12, 'unit': 'TFLOP/s',
+                           'frac': round(fl / tt / peak, 5), 'traffic': None, 'avg_launch_us': round(tt / cnt * 1e6, 2),
+                           'launches_per_step': cnt // 2, 'gemm_launches_per_step': launches,
+                           'gemm_time_ms_per_step': round(tot_t / 2 * 1e3, 3),
+                           'all_gemm_tflops': round(sum(x[0] for x in agg.values()) / tot_t / 1e12, 2)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(os.cpu_count() or 1)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

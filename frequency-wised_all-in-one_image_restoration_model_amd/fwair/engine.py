@@ -1,0 +1,225 @@
+"""Training engine for the MI355X-native AirNet: flat parameter / gradient storage, fused Adam + MoCo EMA,
+whole-step HIP-graph capture and batch-sharded data parallelism over RCCL (torch.distributed backend "nccl").
+
+The reference trains single-GPU, eager, fp32 (train.py:73-96); this is the throughput driver SURVEY.md section 8(e,f)
+asks for.  Per step (train.py:80-96 phase 2):
+    zero grads -> AirNet forward (query encoder, EMA, key encoder, MoCo logits, decoder) -> L1 + w * mean CE ->
+    backward -> [gradient all-reduce] -> Adam -> shadow refresh
+One process per GPU; every replica keeps its own BatchNorm statistics and MoCo queue (the reference has neither
+SyncBN nor a gathered queue -- net/utils/moco.py:55 is commented out), so a replica is exactly a reference run on
+its shard and the only exchange is the mean of the gradients.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import functional as Fn
+from .lib import call
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# loss  (train.py:88-92):  l1(restored, clean) + w * mean_i CE(logits_i, 0)
+# ---------------------------------------------------------------------------------------------------------------
+class TrainLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, restored, clean, logits, w, gscale):
+        """logits: f32 [L, B, 1+K].  Returns f32 [3] = (unused, l1, contrast).  Gradients are pre-multiplied by
+        gscale (1 / world size: a SUM all-reduce then yields the data-parallel mean)."""
+        dev = restored.device
+        restored, clean, logits = restored.contiguous(), clean.contiguous(), logits.contiguous()
+        out = torch.zeros(3, dtype=torch.float32, device=dev)
+        dres = torch.empty_like(restored)
+        dlog = torch.empty_like(logits)
+        L, B, N = logits.shape
+        call('fw_l1_loss', restored, clean, dres, restored.numel(), float(gscale), out[1:2])
+        call('fw_ce0_loss', logits, dlog, L * B, N, float(w) * float(gscale), out[2:3])
+        ctx.save_for_backward(dres, dlog)
+        ctx.w = float(w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dres, dlog = ctx.saved_tensors
+        # d(total) = d(l1) + w d(contrast); the kernels already folded w into dlog.  dout is (1, 0, 0) for total.
+        return dres, None, dlog, None, None
+
+
+def train_loss(restored, clean, logits, w, gscale=1.0):
+    """-> (total [scalar tensor], l1, contrast); total is differentiable (its backward seeds the kernels' gradients)."""
+    v = TrainLossFn.apply(restored, clean, logits, w, gscale)
+    total = v[1] + w * v[2]
+    return total, v[1].detach(), v[2].detach()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# flat storage
+# ---------------------------------------------------------------------------------------------------------------
+def flatten_parameters(params, device=None):
+    """Re-home `params` into one contiguous f32 buffer (each parameter becomes a view).  Returns the flat tensor."""
+    params = list(params)
+    device = device or params[0].device
+    n = sum(p.numel() for p in params)
+    pad = (-n) % 4
+    flat = torch.empty(n + pad, dtype=torch.float32, device=device)
+    if pad:
+        flat[n:].zero_()
+    o = 0
+    with torch.no_grad():
+        for p in params:
+            v = flat[o:o + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            o += p.numel()
+    return flat
+
+
+def attach_flat_grads(params, flat_g):
+    o = 0
+    for p in params:
+        p.grad = flat_g[o:o + p.numel()].view_as(p)
+        o += p.numel()
+
+
+class GradAllReducer:
+    """Mean of the flat gradient buffer over the data-parallel group, in a few large buckets (xGMI is
+    point-to-point: few, large collectives).  Works with any backend (RCCL on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, flat_g, group=None, bucket_elems=64 * 1024 * 1024, wire_dtype=torch.float32):
+        self.flat_g, self.group, self.wire_dtype = flat_g, group, wire_dtype
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        n = flat_g.numel()
+        self.buckets = [(s, min(n, s + bucket_elems)) for s in range(0, n, bucket_elems)]
+        self._wire = None
+        if wire_dtype != torch.float32:
+            self._wire = torch.empty(min(n, bucket_elems), dtype=wire_dtype, device=flat_g.device)
+
+    def __call__(self):
+        if self.world == 1:
+            return
+        works = []
+        for s, e in self.buckets:
+            g = self.flat_g[s:e]
+            if self._wire is None:
+                works.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, g))
+            else:
+                w = self._wire[:e - s]
+                w.copy_(g)
+                dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
+                g.copy_(w)
+        for wk, _, _ in works:
+            wk.wait()                                  # gradients were pre-scaled by 1/world in the loss
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# engine
+# ---------------------------------------------------------------------------------------------------------------
+class TrainEngine:
+    def __init__(self, net, lr=2e-4, contrast_loss_weight=0.6, betas=(0.9, 0.999), eps=1e-8, use_graph=True,
+                 grad_wire_dtype=torch.float32):
+        self.net = net
+        self.w = float(contrast_loss_weight)
+        self.betas, self.eps = betas, eps
+        self.use_graph = use_graph
+        moco = net.E.E
+        enc_q = list(moco.encoder_q.parameters())
+        enc_k = list(moco.encoder_k.parameters())
+        rest = [p for p in net.parameters() if p.requires_grad and all(p is not q for q in enc_q)]
+        self.trainable = enc_q + rest                      # query encoder first: its slice mirrors the key encoder
+        dev = enc_q[0].device
+        assert dev.type == 'cuda', 'TrainEngine needs the HIP device'
+        self.flat_p = flatten_parameters(self.trainable, dev)
+        self.flat_k = flatten_parameters(enc_k, dev)
+        self.n_enc = sum(p.numel() for p in enc_q)
+        self.n = sum(p.numel() for p in self.trainable)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        attach_flat_grads(self.trainable, self.flat_g)
+        self.m = torch.zeros_like(self.flat_p)
+        self.v = torch.zeros_like(self.flat_p)
+        self.hyper = torch.tensor([lr, 1.0, 1.0, 0.0], dtype=torch.float32, device=dev)
+        moco._ema_hook = self._ema
+        self.allreduce = GradAllReducer(self.flat_g, wire_dtype=grad_wire_dtype)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.flat_p, src=0)             # identical replicas at start
+            dist.broadcast(self.flat_k, src=0)
+        Fn.config.shadow_epoch += 1
+        self._graph = None
+        self._static = None
+        self.last = None
+
+    def set_lr(self, lr):
+        self.hyper[0:1].fill_(float(lr))
+
+    def _ema(self):
+        call('fw_ema', 0, self.flat_k, self.flat_p, None, self.n_enc, self.net.E.E.m)
+        Fn.config.shadow_epoch += 1
+
+    def _fwd_bwd(self, xq, xk, clean):
+        self.flat_g.zero_()
+        restored, logits, labels = self.net(x_query=xq, x_key=xk)
+        total, l1, contrast = train_loss(restored, clean, torch.stack(logits, 0), self.w, 1.0 / self.allreduce.world)
+        total.backward()
+        return torch.stack([total.detach(), l1, contrast])
+
+    def _optim(self):
+        call('fw_adam_tick', self.hyper, self.betas[0], self.betas[1])
+        call('fw_adam', 0, self.flat_p, self.flat_g, self.m, self.v, None, self.n, self.hyper, self.betas[0], self.betas[1], self.eps)
+        Fn.config.shadow_epoch += 1
+
+    def step_eager(self, xq, xk, clean):
+        out = self._fwd_bwd(xq, xk, clean)
+        self.allreduce()
+        self._optim()
+        self.last = out
+        return out
+
+    def capture(self, xq, xk, clean, warmup=2):
+        """Warm up eagerly on a side stream, then capture forward+backward (and, single-GPU, the optimizer) into HIP graphs."""
+        self._static = (xq.clone(), xk.clone(), clean.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.step_eager(*self._static)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        single = self.allreduce.world == 1
+        self._g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g1):
+            self._out = self._fwd_bwd(*self._static)
+            if single:
+                self._optim()
+        self._g2 = None
+        if not single:
+            self._g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g2, pool=self._g1.pool()):
+                self._optim()
+        self._graph = True
+
+    def step(self, xq, xk, clean):
+        if not self.use_graph:
+            return self.step_eager(xq, xk, clean)
+        if self._graph is None:
+            self.capture(xq, xk, clean)
+        sq, sk, sc = self._static
+        if xq is not sq:
+            sq.copy_(xq, non_blocking=True); sk.copy_(xk, non_blocking=True); sc.copy_(clean, non_blocking=True)
+        self._g1.replay()
+        if self._g2 is not None:
+            self.allreduce()
+            self._g2.replay()
+        self.last = self._out
+        return self._out
+
+
+def init_distributed():
+    """torchrun-style environment -> (rank, local_rank, world).  Backend "nccl" is RCCL on ROCm."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    return rank, local, world

@@ -1,0 +1,584 @@
+"""Autograd shells around the HIP kernels.  PyTorch supplies the tape, the allocator and the stream; every
+forward/backward body is a sequence of C-ABI calls (fwair.ops) -- there is no eager-PyTorch arithmetic and no
+CPU fallback.  Layout conventions:
+  * the residual stream and every parameter / gradient is f32;
+  * "T" activations (GEMM operands) are f32 or bf16 according to fwair.config.compute_dtype, stored as
+    [tokens, C] views of [tokens, roundup(C, 8)] buffers so that every row starts 16-byte aligned.
+"""
+import weakref
+
+import torch
+
+from . import ops
+from .lib import call, dt
+
+
+class config:
+    compute_dtype = torch.float32       # torch.float32 | torch.bfloat16
+    shadow_epoch = 0                    # bumped by the engine after a fused optimizer step
+
+
+def act_empty(rows, cols, dtype, device):
+    """[rows, cols] view of a buffer whose row stride is a multiple of 8 elements."""
+    ld = (cols + 7) // 8 * 8
+    return torch.empty((rows, ld), dtype=dtype, device=device)[:, :cols]
+
+
+def aligned(t):
+    """Gradients handed over by autograd may be freshly summed contiguous tensors: re-home rows that are not
+    16-byte aligned (only possible for bf16 with C % 8 != 0)."""
+    if t.stride(1) == 1 and (t.stride(0) * t.element_size()) % 16 == 0 and t.data_ptr() % 16 == 0:
+        return t
+    out = act_empty(t.shape[0], t.shape[1], t.dtype, t.device)
+    out.copy_(t)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# low-precision / re-laid-out shadows of parameters
+# ---------------------------------------------------------------------------------------------------------------
+_shadow = {}          # id(param) -> (weakref(param), {(kind, dtype): (stamp, tensor)}); tensors cannot be dict keys (== is elementwise)
+
+
+def shadow(param, kind='plain'):
+    """Operand view of a parameter in the compute dtype.
+    kind: 'plain' [N, K];  'conv4' [Cout, Cin, 4, 4] -> [Cout, 16*Cin] (K order ky, kx, ci);
+          'convT2' [Cin, Cout, 2, 2] -> [4*Cout, Cin] (row order i, j, co)."""
+    dtype = config.compute_dtype
+    p = param.detach()
+    if kind == 'plain' and dtype == torch.float32:
+        w = p.reshape(p.shape[0], -1)
+        if (w.stride(0) * 4) % 16 == 0:
+            return w
+    slot = _shadow.get(id(param))
+    ent = slot[1] if slot is not None and slot[0]() is param else None
+    key = (kind, dtype)
+    stamp = (param._version, config.shadow_epoch, p.data_ptr())
+    if ent is not None and key in ent and ent[key][0] == stamp:
+        return ent[key][1]
+    if kind == 'plain':
+        n, k = p.shape[0], p[0].numel()
+        out = act_empty(n, k, dtype, p.device)
+        call('fw_cast_rows', dt(dtype), p.reshape(n, k), k, out, out.stride(0), n, k, None, 1)
+    elif kind == 'conv4':
+        co, ci = p.shape[0], p.shape[1]
+        out = torch.empty((co, 16 * ci), dtype=dtype, device=p.device)
+        ops.permute3(p.contiguous(), out, (co, ci, 16), (16 * ci, 1, ci))
+    elif kind == 'convT2':
+        ci, co = p.shape[0], p.shape[1]
+        out = torch.empty((4 * co, ci), dtype=dtype, device=p.device)
+        ops.permute3(p.contiguous(), out, (ci, co, 4), (1, ci, co * ci))
+    else:
+        raise ValueError(kind)
+    if ent is None:
+        ent = {}
+        pid = id(param)
+        _shadow[pid] = (weakref.ref(param, lambda _r, pid=pid: _shadow.pop(pid, None)), ent)
+    ent[key] = (stamp, out)
+    return out
+
+
+def _zeros(shape, device):
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
+def _wgrad(g, x, n, k, m, x_op=0):
+    """dW[n][k] = sum_m g[m][n] * op(x)[m][k]  (both operands reduction-major)."""
+    dw = _zeros((n, k), g.device)
+    ops.gemm(g, x, n, k, m, x_trans=True, w_trans=True, w_op=x_op, out=dw, accumulate=True,
+             splitk=ops.pick_splitk(n, k, m, g.dtype))
+    return dw
+
+
+def _bgrad(g, n):
+    db = _zeros((n,), g.device)
+    ops.colsum(g, db)
+    return db
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LayerNorm : f32 stream -> T
+# ---------------------------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        rows, C = x.shape
+        y = act_empty(rows, C, config.compute_dtype, x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        call('fw_layernorm_fwd', dt(y.dtype), x, x.stride(0), gamma, beta, y, y.stride(0), mean, rstd, rows, C, 1e-5)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = aligned(dy)
+        dg, db = _zeros(gamma.shape, x.device), _zeros(gamma.shape, x.device)
+        dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db)
+        return dx, dg, db
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Linear : T -> T | f32 (+ residual stream, DropPath row scale, GELU on the input, LeakyReLU on the output)
+# ---------------------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = [residual +] rowscale * (op(x) W^T + b).   x: T [M, K];  W: f32 parameter [N, K].
+    x_gelu: op = GELU (LeFF: the stored tensors are pre-activations).  out_f32: y is the f32 stream."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, rowscale, rows_per_scale, x_gelu, out_f32):
+        M, K = x.shape
+        N = weight.shape[0]
+        w = shadow(weight)
+        if residual is not None or out_f32:
+            y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        else:
+            y = act_empty(M, N, x.dtype, x.device)
+        ops.gemm(x, w, M, N, K, x_op=int(x_gelu), out=y, bias=bias, rowscale=rowscale, rows_per_scale=rows_per_scale,
+                 residual=residual)
+        ctx.save_for_backward(x, weight, rowscale)
+        ctx.cfg = (rows_per_scale, x_gelu, residual is not None, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, rowscale = ctx.saved_tensors
+        rows_per_scale, x_gelu, has_res, has_bias = ctx.cfg
+        M, K = x.shape
+        N = weight.shape[0]
+        if dy.dtype == torch.float32 and x.dtype != torch.float32 or rowscale is not None:
+            g = act_empty(M, N, x.dtype, x.device)
+            call('fw_cast_rows', dt(x.dtype), dy, dy.stride(0), g, g.stride(0), M, N, rowscale, rows_per_scale)
+        else:
+            g = aligned(dy)
+        dw = _wgrad(g, x, N, K, M, x_op=int(x_gelu)).view_as(weight) if ctx.needs_input_grad[1] else None
+        db = _bgrad(g, N) if has_bias and ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = act_empty(M, K, x.dtype, x.device)
+            ops.gemm(g, shadow(weight), M, K, N, w_trans=True, out=dx, act=2 if x_gelu else 0, aux=x if x_gelu else None)
+        return dx, dw, db, (dy if has_res else None), None, None, None, None
+
+
+def linear(x, weight, bias=None, residual=None, rowscale=None, rows_per_scale=1, x_gelu=False, out_f32=False):
+    return LinearFn.apply(x, weight, bias, residual, rowscale, rows_per_scale, x_gelu, out_f32)
+
+
+class QKVFn(torch.autograd.Function):
+    """qkv buffer [M, Cp + 2C] = [ x Wq^T + bq | pad | x Wkv^T + bkv ],  Cp = roundup(C, 8)
+    (decoder_Uformer.py:121-124: to_q and to_kv outputs, k = kv[:, :C], v = kv[:, C:])."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wkv, bkv):
+        M, K = x.shape
+        C = wq.shape[0]
+        Cp = (C + 7) // 8 * 8
+        buf = act_empty(M, Cp + 2 * C, x.dtype, x.device)
+        ops.gemm(x, shadow(wq), M, C, K, out=buf[:, :C], bias=bq)
+        ops.gemm(x, shadow(wkv), M, 2 * C, K, out=buf[:, Cp:], bias=bkv)
+        ctx.save_for_backward(x, wq, wkv)
+        return buf
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        x, wq, wkv = ctx.saved_tensors
+        M, K = x.shape
+        C = wq.shape[0]
+        Cp = (C + 7) // 8 * 8
+        dbuf = aligned(dbuf)
+        dq, dkv = dbuf[:, :C], dbuf[:, Cp:]
+        dwq = _wgrad(dq, x, C, K, M)
+        dwkv = _wgrad(dkv, x, 2 * C, K, M)
+        dbq, dbkv = _bgrad(dq, C), _bgrad(dkv, 2 * C)
+        tmp = torch.empty((M, K), dtype=torch.float32, device=x.device)
+        ops.gemm(dq, shadow(wq), M, K, C, w_trans=True, out=tmp)
+        dx = act_empty(M, K, x.dtype, x.device)
+        ops.gemm(dkv, shadow(wkv), M, K, 2 * C, w_trans=True, out=dx, residual=tmp)
+        return dx, dwq, dbq, dwkv, dbkv
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# window attention
+# ---------------------------------------------------------------------------------------------------------------
+class WindowAttnFn(torch.autograd.Function):
+    """qkv: buffer of QKVFn.  tables: f32 [ntab, 225, heads].  coef: f32 [B, heads, 3] or None."""
+
+    @staticmethod
+    def forward(ctx, qkv, tables, coef, geo):
+        C, B, H, W, heads, L, mode, shift, lfs = geo
+        D = C // heads
+        Cp = (C + 7) // 8 * 8
+        rows = qkv.shape[0]
+        nkt = 1 if mode == 0 else L - 1
+        out = act_empty(rows, C, qkv.dtype, qkv.device)
+        lse = torch.empty((B * (H // 8) * (W // 8) * L * heads, 64), dtype=torch.float32, device=qkv.device)
+        tab = ops._lfs.device_table(qkv.dtype, qkv.device) if lfs == 2 else None
+        call('fw_attn_fwd', dt(qkv.dtype), D, nkt, lfs, qkv, qkv[:, Cp:], qkv[:, Cp + C:], qkv.stride(0), out, out.stride(0),
+             lse, tables, coef, tab, B, H, W, heads, L, mode, shift, float(D) ** -0.5)
+        ctx.save_for_backward(qkv, tables, coef, out, lse)
+        ctx.geo = geo
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, tables, coef, out, lse = ctx.saved_tensors
+        C, B, H, W, heads, L, mode, shift, lfs = ctx.geo
+        D = C // heads
+        Cp = (C + 7) // 8 * 8
+        rows = qkv.shape[0]
+        nkt = 1 if mode == 0 else L - 1
+        dout = aligned(dout)
+        dqkv = act_empty(rows, qkv.shape[1], qkv.dtype, qkv.device)
+        d2 = act_empty(rows, qkv.shape[1], qkv.dtype, qkv.device) if nkt == 2 else None
+        dtab = _zeros(tables.shape, qkv.device)
+        dcoef = _zeros(coef.shape, qkv.device) if coef is not None else None
+        tab = ops._lfs.device_table(qkv.dtype, qkv.device) if lfs == 2 else None
+        call('fw_attn_bwd', dt(qkv.dtype), D, nkt, lfs, qkv, qkv[:, Cp:], qkv[:, Cp + C:], qkv.stride(0), out, out.stride(0),
+             dout, dout.stride(0), lse, tables, coef, tab, dqkv, dqkv[:, Cp:], dqkv[:, Cp + C:],
+             d2[:, Cp:] if d2 is not None else None, d2[:, Cp + C:] if d2 is not None else None, dqkv.stride(0), dtab, dcoef,
+             B, H, W, heads, L, mode, shift, float(D) ** -0.5)
+        if nkt == 2:
+            call('fw_add_rows', dt(qkv.dtype), d2[:, Cp:], d2.stride(0), dqkv[:, Cp:], dqkv.stride(0), rows, 2 * C)
+        return dqkv, dtab, dcoef, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LeFF depthwise conv (input and output are pre-activations; GELU is applied on load by the consumers)
+# ---------------------------------------------------------------------------------------------------------------
+class DwConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h1, weight, bias, B, H, W):
+        C = h1.shape[1]
+        h2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
+        call('fw_dwconv_fwd', dt(h1.dtype), h1, h1.stride(0), weight, bias, h2, h2.stride(0), B, H, W, C)
+        ctx.save_for_backward(h1, weight)
+        ctx.geo = (B, H, W)
+        return h2
+
+    @staticmethod
+    def backward(ctx, dh2):
+        h1, weight = ctx.saved_tensors
+        B, H, W = ctx.geo
+        C = h1.shape[1]
+        dh2 = aligned(dh2)
+        dw, db = _zeros((C, 9), h1.device), _zeros((C,), h1.device)
+        dh1 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
+        call('fw_dwconv_bwd', dt(h1.dtype), dh2, dh2.stride(0), h1, h1.stride(0), weight, dh1, dh1.stride(0), dw, db, B, H, W, C)
+        return dh1, dw.view_as(weight), db, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# convolutions
+# ---------------------------------------------------------------------------------------------------------------
+class DownsampleFn(torch.autograd.Function):
+    """Conv2d k4 s2 p1 on the token stream (decoder_Uformer.py:423-430): im2col + GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, B, H, W):
+        C, Co = x.shape[1], weight.shape[0]
+        col = ops.im2col4(x, B, H, W, config.compute_dtype)
+        y = torch.empty((col.shape[0], Co), dtype=torch.float32, device=x.device)
+        ops.gemm(col, shadow(weight, 'conv4'), col.shape[0], Co, 16 * C, out=y, bias=bias)
+        ctx.save_for_backward(x, weight)
+        ctx.geo = (B, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, H, W = ctx.geo
+        C, Co = x.shape[1], weight.shape[0]
+        Mo = dy.shape[0]
+        g = ops.cast_rows(dy, config.compute_dtype) if config.compute_dtype != torch.float32 else aligned(dy)
+        col = ops.im2col4(x, B, H, W, config.compute_dtype)
+        dwk = _wgrad(g, col, Co, 16 * C, Mo)
+        dw = _zeros((Co, C, 16), x.device)
+        ops.permute3(dwk, dw, (Co, 16, C), (16 * C, 1, 16), accumulate=True)
+        del col
+        dcol = ops.gemm(g, shadow(weight, 'conv4'), Mo, 16 * C, Co, w_trans=True)
+        dx = ops.col2im4(dcol, B, H, W, C)
+        return dx, dw.view_as(weight), _bgrad(dy, Co), None, None, None
+
+
+class UpsampleCatFn(torch.autograd.Function):
+    """ConvTranspose2d k2 s2 (decoder_Uformer.py:443-449) followed by torch.cat([up, skip], -1) (:1162)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, weight, bias, B, H, W):
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        Cs = skip.shape[1]
+        xq = ops.cast_rows(x, config.compute_dtype) if config.compute_dtype != torch.float32 else x
+        g = ops.gemm(xq, shadow(weight, 'convT2'), x.shape[0], 4 * Cout, Cin)
+        out = torch.empty((4 * x.shape[0], Cout + Cs), dtype=torch.float32, device=x.device)
+        ops.pixel_shuffle(g, bias, out[:, :Cout], B, H, W, Cout)
+        ops.copy_rows(skip, out[:, Cout:])
+        ctx.save_for_backward(x, weight)
+        ctx.geo = (B, H, W, Cs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dcat):
+        x, weight = ctx.saved_tensors
+        B, H, W, Cs = ctx.geo
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        M = x.shape[0]
+        dg = ops.pixel_unshuffle(dcat[:, :Cout], B, H, W, Cout, config.compute_dtype)
+        xq = ops.cast_rows(x, config.compute_dtype) if config.compute_dtype != torch.float32 else x
+        dwt = _wgrad(dg, xq, 4 * Cout, Cin, M)
+        dw = _zeros((Cin, Cout, 4), x.device)
+        ops.permute3(dwt, dw, (4, Cout, Cin), (1, 4, Cout * 4), accumulate=True)
+        dx = ops.gemm(dg, shadow(weight, 'convT2'), M, Cin, 4 * Cout, w_trans=True, out_dtype=torch.float32)
+        db = _zeros((Cout,), x.device)
+        ops.colsum(dcat[:, :Cout], db)
+        dskip = torch.empty((dcat.shape[0], Cs), dtype=torch.float32, device=x.device)
+        ops.copy_rows(dcat[:, Cout:], dskip)
+        return dx, dskip, dw.view_as(weight), db, None, None, None
+
+
+class InputProjFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, weight, bias):
+        B, _, H, W = img.shape
+        C = weight.shape[0]
+        img = img.contiguous()
+        out = torch.empty((B * H * W, C), dtype=torch.float32, device=img.device)
+        call('fw_inproj_fwd', img, weight, bias, out, C, B, H, W, C, 0.01)
+        ctx.save_for_backward(img, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        img, weight, out = ctx.saved_tensors
+        B, _, H, W = img.shape
+        C = weight.shape[0]
+        dw, db = _zeros(weight.shape, img.device), _zeros((C,), img.device)
+        dy = dy.contiguous()
+        call('fw_inproj_bwd', img, out, C, dy, dy.stride(0), dw, db, B, H, W, C, 0.01)
+        return None, dw, db
+
+
+class OutputProjFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fea, weight, bias, img):
+        B, _, H, W = img.shape
+        C = fea.shape[1]
+        img = img.contiguous()
+        out = torch.empty_like(img)
+        call('fw_outproj_fwd', fea, fea.stride(0), weight, bias, img, out, B, H, W, C)
+        ctx.save_for_backward(fea, weight)
+        ctx.geo = (B, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        fea, weight = ctx.saved_tensors
+        B, H, W = ctx.geo
+        C = fea.shape[1]
+        dout = dout.contiguous()
+        dfea = torch.empty((fea.shape[0], C), dtype=torch.float32, device=fea.device)
+        dw, db = _zeros(weight.shape, fea.device), _zeros((3,), fea.device)
+        call('fw_outproj_bwd', dout, fea, fea.stride(0), weight, dfea, C, dw, db, B, H, W, C)
+        return dfea, dw, db, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# encoder contrastive head
+# ---------------------------------------------------------------------------------------------------------------
+class BnLreluGapFn(torch.autograd.Function):
+    """fea: T [B*64, ED*256] viewed as [B][ED][P] -> BatchNorm2d -> LeakyReLU(0.1) -> mean over P  (encoder_Uformer.py:978-982)."""
+
+    @staticmethod
+    def forward(ctx, fea, gamma, beta, rmean, rvar, nbt, B, training):
+        ED = gamma.shape[0]
+        P = fea.numel() // (B * ED)
+        assert fea.is_contiguous()
+        dev = fea.device
+        gap = torch.empty((B, ED), dtype=torch.float32, device=dev)
+        part = torch.empty((ED, B, 2), dtype=torch.float32, device=dev) if training else None
+        saved = torch.empty((ED, 2), dtype=torch.float32, device=dev) if training else None
+        call('fw_bn_lrelu_gap_fwd', dt(fea.dtype), fea, gamma, beta, rmean, rvar, nbt, part, saved, gap, B, ED, P, int(training),
+             1e-5, 0.1, 0.1)
+        ctx.save_for_backward(fea, gamma, beta, saved)
+        ctx.geo = (B, ED, P, training)
+        return gap
+
+    @staticmethod
+    def backward(ctx, dgap):
+        fea, gamma, beta, saved = ctx.saved_tensors
+        B, ED, P, training = ctx.geo
+        assert training, 'backward through eval-mode BatchNorm is not part of the hot path'
+        dev = fea.device
+        part2 = torch.empty((ED, B, 2), dtype=torch.float32, device=dev)
+        dfea = torch.empty_like(fea)
+        dg, db = _zeros((ED,), dev), _zeros((ED,), dev)
+        call('fw_bn_lrelu_gap_bwd', dt(fea.dtype), fea, gamma, beta, saved, dgap.contiguous(), part2, dfea, dg, db, B, ED, P, 0.1)
+        return dfea, dg, db, None, None, None, None, None
+
+
+class LreluFn(torch.autograd.Function):
+    """f32 -> T LeakyReLU (head MLPs)."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = x.contiguous()
+        y = act_empty(x.shape[0], x.shape[1], config.compute_dtype, x.device)
+        if y.stride(0) != x.shape[1]:
+            y = torch.empty(x.shape, dtype=config.compute_dtype, device=x.device)
+        call('fw_lrelu_fwd', dt(y.dtype), x, y, x.numel(), slope)
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        call('fw_lrelu_bwd', dt(dy.dtype), dy, x, dx, x.numel(), ctx.slope)
+        return dx, None
+
+
+class CastFn(torch.autograd.Function):
+    """f32 -> T (identity in f32 mode); backward T -> f32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        if config.compute_dtype == torch.float32:
+            return x.view_as(x)
+        return ops.cast_rows(x, config.compute_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy.dtype == torch.float32:
+            return dy
+        dy = dy.contiguous()
+        out = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
+        ops.permute3(dy, out, (1, 1, dy.numel()), (0, 0, 1))
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MoCo logits
+# ---------------------------------------------------------------------------------------------------------------
+class MocoLogitsFn(torch.autograd.Function):
+    """q, k: f32 [L, B, ED] (un-normalised); queue: f32 [L, ED, K] -> logits [L, B, 1+K] (moco.py:127-156)."""
+
+    @staticmethod
+    def forward(ctx, q, k, queue, T):
+        L, B, ED = q.shape
+        K = queue.shape[2]
+        q, k = q.contiguous(), k.contiguous()
+        qsnap = queue.clone()                      # moco.py:149 clones the queue before it is overwritten
+        logits = torch.empty((L, B, 1 + K), dtype=torch.float32, device=q.device)
+        khat = torch.empty((L, B, ED), dtype=torch.float32, device=q.device)
+        call('fw_moco_logits', q, k, qsnap, logits, khat, L, B, ED, K, 1.0 / T)
+        ctx.save_for_backward(q, khat, qsnap)
+        ctx.T = T
+        ctx.mark_non_differentiable(khat)
+        return logits, khat
+
+    @staticmethod
+    def backward(ctx, dlogits, _):
+        q, khat, qsnap = ctx.saved_tensors
+        L, B, ED = q.shape
+        dq = torch.empty_like(q)
+        call('fw_moco_logits_bwd', q, khat, qsnap, dlogits.contiguous(), dq, L, B, ED, qsnap.shape[2], 1.0 / ctx.T)
+        return dq, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LFS lambda heads of all decoder blocks in one launch
+# ---------------------------------------------------------------------------------------------------------------
+_lfs_tables = {}
+
+
+class LfsLambdaFn(torch.autograd.Function):
+    """inter: f32 [nb1*B*64, C] (bands 1.. of the encoder output).  params: per block, per band, the 8 tensors
+    (ln.w, ln.b, lin.w, lin.b, mlp0.w, mlp0.b, mlp2.w, mlp2.b).  Returns the flat (a, b, c) coefficient buffer."""
+
+    @staticmethod
+    def forward(ctx, inter, meta, *params):
+        heads_list, B, nb1 = meta
+        dev = inter.device
+        C = inter.shape[1]
+        nblk = len(heads_list)
+        inter = inter.contiguous()
+        xbar = torch.empty((nb1 * B, C), dtype=torch.float32, device=dev)
+        stats = torch.empty((nb1 * B, 64, 2), dtype=torch.float32, device=dev)
+        call('fw_lfs_xbar', inter, xbar, stats, nb1, B, 64, C, 1e-5)
+        key = (tuple(p.data_ptr() for p in params), B, nb1, str(dev))
+        tabs = _lfs_tables.get(key)
+        if tabs is None:                    # host-built once per parameter placement (never inside a graph capture)
+            ptab = torch.zeros((nblk, 2, 8), dtype=torch.int64)
+            it = iter(params)
+            for bi in range(nblk):
+                for band in range(nb1):
+                    for j in range(8):
+                        ptab[bi, band, j] = next(it).data_ptr()
+            offs = [0]
+            for h in heads_list:
+                offs.append(offs[-1] + B * h * 3)
+            total = sum(p.numel() for p in params)
+            gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+            gt, o, k = torch.zeros((nblk, 2, 8), dtype=torch.int64), 0, 0
+            for bi in range(nblk):
+                for band in range(nb1):
+                    for j in range(8):
+                        gt[bi, band, j] = gflat.data_ptr() + 4 * o
+                        o += params[k].numel()
+                        k += 1
+            tabs = (ptab.to(dev), torch.tensor(heads_list, dtype=torch.int32).to(dev),
+                    torch.tensor(offs[:-1], dtype=torch.int64).to(dev), offs[-1], gflat, gt.to(dev))
+            _lfs_tables.clear()
+            _lfs_tables[key] = tabs
+        ptab, heads, coef_off, ncoef, gflat, gt = tabs
+        offs = [ncoef]
+        coef = torch.empty(offs[-1], dtype=torch.float32, device=dev)
+        save = torch.empty((nblk, 2, B, 16, 3), dtype=torch.float32, device=dev)
+        call('fw_lfs_lambda', xbar, ptab, heads, coef_off, coef, save, nblk, B, C, nb1)
+        ctx.save_for_backward(inter, xbar, stats, ptab, heads, coef_off, save, *params)
+        ctx.meta = meta
+        ctx.gbuf = (gflat, gt)
+        return coef
+
+    @staticmethod
+    def backward(ctx, dcoef):
+        inter, xbar, stats, ptab, heads, coef_off, save = ctx.saved_tensors[:7]
+        params = ctx.saved_tensors[7:]
+        heads_list, B, nb1 = ctx.meta
+        dev = inter.device
+        C = inter.shape[1]
+        nblk = len(heads_list)
+        gflat, gt = ctx.gbuf
+        gflat.zero_()
+        grads, o = [], 0
+        for p in params:
+            grads.append(gflat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        dxbar = torch.zeros_like(xbar)
+        call('fw_lfs_lambda_bwd', xbar, ptab, gt, heads, coef_off, dcoef.contiguous(), save, dxbar, nblk, B, C, nb1)
+        dinter = torch.zeros_like(inter)
+        call('fw_lfs_xbar_bwd', inter, stats, dxbar, dinter, nb1, B, 64, C)
+        return (dinter, None) + tuple(grads)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# DropPath row scales (timm semantics: floor(keep + U) / keep per sample)
+# ---------------------------------------------------------------------------------------------------------------
+_dp_override = None
+
+
+def set_droppath_override(fn):
+    """fn(name, nsamples, rate, device) -> f32 [nsamples] or None; tests inject recorded masks here."""
+    global _dp_override
+    _dp_override = fn
+
+
+def droppath_scale(name, nsamples, rate, training, device):
+    if not training or rate == 0.0:
+        return None
+    if _dp_override is not None:
+        return _dp_override(name, nsamples, rate, device)
+    keep = 1.0 - rate
+    return torch.floor(keep + torch.rand(nsamples, device=device)) / keep

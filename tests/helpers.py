@@ -1,0 +1,59 @@
+"""Shared test helpers: golden loading, seeded inputs (same recipe as tests/golden/make_golden.py)."""
+import json
+import os
+import types
+
+import numpy as np
+import torch
+
+import airnet_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+VARIANTS = {
+    'all3': dict(degradation_embedding_method=['all_3_bands'], L=3, encoder_msa_type='freq'),
+    'allDC': dict(degradation_embedding_method=['all_DC'], L=3, encoder_msa_type='freq'),
+    'all2_L2': dict(degradation_embedding_method=['all_2_bands'], L=2, encoder_msa_type='freq'),
+    'all3_origin': dict(degradation_embedding_method=['all_3_bands'], L=3, encoder_msa_type='origin'),
+}
+
+
+def load(name):
+    with np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False) as z:
+        return {k: (torch.from_numpy(np.asarray(z[k])) if z[k].dtype.kind != 'U' else z[k]) for k in z.files}
+
+
+def schema(variant):
+    with open(os.path.join(GOLDEN, 'schema.json')) as f:
+        return [tuple(e) for e in json.load(f)[variant]]
+
+
+def rnd(name, shape, scale=1.0):
+    return O.seeded_tensor('input.' + name, shape) / 0.02 * scale
+
+
+def synth_batch(B, size, tag):
+    clean = torch.sigmoid(rnd(tag + 'clean', (B, 3, size, size), 1.5))
+    q = (clean + rnd(tag + 'nq', clean.shape, 25 / 255.)).clamp(0, 1)
+    k = (clean + rnd(tag + 'nk', clean.shape, 25 / 255.)).clamp(0, 1)
+    return clean, q, k
+
+
+def make_opt(variant, batch_size=2, **kw):
+    d = dict(L=3, encoder_dim=256, encoder_embed_dim=28, embed_dim=56, batch_size=batch_size, patch_size=128,
+             contrast_loss_weight=0.6, encoder_type='Uformer', decoder_type='Uformer', debug_mode=False,
+             frequency_decompose_type='none', learnable_modulator=False, compute_dtype='fp32')
+    d.update(VARIANTS[variant])
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def close(a, b, tol, what=''):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, f'{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}'
+    assert torch.isfinite(a).all(), f'{what}: non-finite values'
+    scale = max(b.abs().max().item(), 1e-12)
+    err = (a - b).abs().max().item() / scale
+    assert err < tol, f'{what}: rel-to-max err {err:.3e} >= {tol:.1e} (scale {scale:.3e})'
+    return err

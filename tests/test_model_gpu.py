@@ -1,0 +1,123 @@
+"""GPU parity of the whole MI355X-native AirNet (HIP kernels behind net.model.AirNet) against
+  (a) goldens produced by the REAL reference (tests/golden/model_*.npz), and
+  (b) the CPU oracle on the same seeded weights / inputs.
+fp32 compute: tensors within 1e-4 relative (north_star), PSNR within 0.01 dB.  bf16 compute: PSNR within
+0.01 dB of the reference value, loss within 2 %.  DropPath is neutralised exactly as in the golden run."""
+import pytest
+import torch
+
+import airnet_oracle as O
+from helpers import VARIANTS, close, load, make_opt, schema, synth_batch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def build(variant, dtype='fp32', batch_size=2):
+    from net.model import AirNet
+    from fwair import functional as Fn
+    opt = make_opt(variant, batch_size=batch_size, compute_dtype=dtype)
+    net = AirNet(opt)
+    st = O.fill_state_seeded(schema(variant))
+    sd = net.state_dict()
+    for k in sd:
+        if st.get(k) is not None and sd[k].is_floating_point():
+            sd[k] = st[k]
+    net.load_state_dict(sd)
+    Fn.set_droppath_override(lambda name, n, rate, device: None)      # DropPath off (goldens were made that way)
+    return net.to(DEV), opt
+
+
+@pytest.mark.parametrize('variant', list(VARIANTS))
+def test_eval_forward_fp32(variant):
+    g = load(f'model_{variant}')
+    net, opt = build(variant)
+    clean, q, k = synth_batch(2, 128, 'model.')
+    net.eval()
+    with torch.no_grad():
+        out = net(x_query=q.to(DEV), x_key=q.to(DEV))
+    err = close(out, g['restored_eval'], 1e-4, 'restored_eval vs reference golden')
+    assert abs(O.psnr(out.cpu(), clean) - float(g['psnr_eval'])) < 0.01
+    print(f'{variant}: eval rel err {err:.2e}')
+
+
+@pytest.mark.parametrize('variant', ['all3', 'all2_L2'])
+def test_train_step_fp32(variant):
+    g = load(f'model_{variant}')
+    net, opt = build(variant)
+    clean, q, k = synth_batch(2, 128, 'model.')
+    net.train()
+    restored, logits, labels = net(x_query=q.to(DEV), x_key=k.to(DEV))
+    close(restored, g['restored_train'], 1e-4, 'restored_train')
+    close(torch.stack(logits), g['logits'], 2e-4, 'logits')
+    CE = torch.nn.CrossEntropyLoss()
+    contrast = sum(CE(logits[i], labels[i]) for i in range(opt.L)) / opt.L
+    loss = torch.nn.L1Loss()(restored, clean.to(DEV)) + opt.contrast_loss_weight * contrast
+    close(loss, g['loss'], 1e-4, 'loss')
+    loss.backward()
+    names = [str(n) for n in g['grad_names']]
+    params = dict(net.named_parameters())
+    norms = torch.tensor([params[n].grad.norm().item() for n in names])
+    rel = ((norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(1e-12))
+    worst = int(rel.argmax())
+    assert rel.max() < 5e-3, f'grad norm of {names[worst]}: {norms[worst]:.6e} vs {g["grad_norms"][worst]:.6e}'
+    for key, val in g.items():
+        if key.startswith('g.'):
+            close(params[key[2:]].grad, val, 5e-3, key)
+    close(net.E.E.queue, g['queue_after'], 1e-4, 'queue')
+    assert int(net.E.E.queue_ptr) == int(g['queue_ptr_after'])
+    close(net.E.E.encoder_q.norm[0][0].running_mean, g['bn_q0_running_mean'], 1e-3, 'bn running mean (q)')
+    close(net.E.E.encoder_q.norm[0][0].running_var, g['bn_q0_running_var'], 1e-3, 'bn running var (q)')
+    close(net.E.E.encoder_k.norm[0][0].running_mean, g['bn_k0_running_mean'], 1e-3, 'bn running mean (k)')
+
+
+def test_eval_and_train_bf16():
+    g = load('model_all3')
+    net, opt = build('all3', 'bf16')
+    clean, q, k = synth_batch(2, 128, 'model.')
+    net.eval()
+    with torch.no_grad():
+        out = net(x_query=q.to(DEV), x_key=q.to(DEV))
+    assert torch.isfinite(out).all()
+    assert abs(O.psnr(out.cpu(), clean) - float(g['psnr_eval'])) < 0.01, (O.psnr(out.cpu(), clean), float(g['psnr_eval']))
+    close(out, g['restored_eval'], 2e-2, 'bf16 restored_eval')
+    net.train()
+    restored, logits, labels = net(x_query=q.to(DEV), x_key=k.to(DEV))
+    CE = torch.nn.CrossEntropyLoss()
+    contrast = sum(CE(logits[i], labels[i]) for i in range(opt.L)) / opt.L
+    loss = torch.nn.L1Loss()(restored, clean.to(DEV)) + opt.contrast_loss_weight * contrast
+    assert abs(float(loss) - float(g['loss'])) / float(g['loss']) < 2e-2
+    loss.backward()
+    names = [str(n) for n in g['grad_names']]
+    params = dict(net.named_parameters())
+    norms = torch.tensor([params[n].grad.norm().item() for n in names])
+    assert torch.isfinite(norms).all()
+    rel = ((norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(1e-12))
+    big = g['grad_norms'] > g['grad_norms'].max() * 1e-3
+    assert rel[big].median() < 5e-2, f'median relative grad-norm deviation {rel[big].median():.3e}'
+
+
+def test_moco_three_steps_fp32():
+    """EMA, queue rotation and pointer wrap over 4 encoder-only steps with SGD in between (tests/golden/moco_steps.npz)."""
+    g = load('moco_steps')
+    net, opt = build('all3')
+    net.train()
+    CE = torch.nn.CrossEntropyLoss()
+    probe = ['uformer.input_proj.proj.0.weight', 'mlp.0.2.weight', 'uformer.conv.blocks.1.mlp.linear2.0.bias']
+    for step in range(4):
+        _, q, k = synth_batch(2, 128, f'moco{step}.')
+        _, logits, labels, inter = net.E(x_query=q.to(DEV), x_key=k.to(DEV))
+        loss = sum(CE(logits[i], labels[i]) for i in range(3)) / 3
+        for p in net.parameters():
+            p.grad = None
+        loss.backward()
+        with torch.no_grad():
+            for p in net.E.E.encoder_q.parameters():
+                if p.grad is not None:
+                    p -= 0.05 * p.grad
+        close(torch.stack(logits), g[f'logits{step}'], 1e-3, f'logits step {step}')
+        close(net.E.E.queue, g[f'queue{step}'], 1e-3, f'queue step {step}')
+        assert int(net.E.E.queue_ptr) == int(g[f'ptr{step}'])
+        ksd = net.E.E.encoder_k.state_dict()
+        for n in probe:
+            close(ksd[n], g[f'k{step}.' + n], 1e-4, f'EMA {n} step {step}')

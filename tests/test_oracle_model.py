@@ -1,0 +1,46 @@
+"""Whole-model oracle (oracle/airnet_oracle.py) against goldens produced by the REAL reference: eval output,
+PSNR, train-mode loss / logits / restored, per-parameter gradient norms, MoCo queue and BN running stats."""
+import pytest
+import torch
+
+import airnet_oracle as O
+from helpers import VARIANTS, close, load, make_opt, schema, synth_batch
+
+
+@pytest.mark.parametrize('variant', list(VARIANTS))
+def test_eval_forward(variant):
+    g = load(f'model_{variant}')
+    st = O.fill_state_seeded(schema(variant))
+    opt = make_opt(variant)
+    clean, q, k = synth_batch(2, 128, 'model.')
+    with torch.no_grad():
+        out = O.airnet_forward(st, opt, q, q, False)
+    close(out, g['restored_eval'], 1e-4, 'restored_eval')
+    assert abs(O.psnr(out, clean) - float(g['psnr_eval'])) < 1e-3
+
+
+@pytest.mark.parametrize('variant', ['all3', 'all2_L2'])
+def test_train_step(variant):
+    g = load(f'model_{variant}')
+    st = O.fill_state_seeded(schema(variant))
+    names = [str(n) for n in g['grad_names']]
+    for n in names:
+        st[n] = st[n].clone().requires_grad_(True)
+    opt = make_opt(variant)
+    clean, q, k = synth_batch(2, 128, 'model.')
+    restored, logits, labels = O.airnet_forward(st, opt, q, k, True)
+    loss, l1, contrast = O.training_loss(opt, restored, logits, labels, clean)
+    close(restored, g['restored_train'], 1e-4, 'restored_train')
+    close(torch.stack(logits), g['logits'], 1e-4, 'logits')
+    close(loss, g['loss'], 1e-5, 'loss')
+    loss.backward()
+    norms = torch.tensor([st[n].grad.norm().item() for n in names])
+    close(norms, g['grad_norms'], 2e-3, 'per-parameter grad norms')
+    for key, val in g.items():
+        if key.startswith('g.'):
+            close(st[key[2:]].grad, val, 2e-3, key)
+    close(st['E.E.queue'], g['queue_after'], 1e-5, 'queue')
+    assert int(st['E.E.queue_ptr']) == int(g['queue_ptr_after'])
+    close(st['E.E.encoder_q.norm.0.0.running_mean'], g['bn_q0_running_mean'], 1e-4, 'bn running mean (q)')
+    close(st['E.E.encoder_q.norm.0.0.running_var'], g['bn_q0_running_var'], 1e-4, 'bn running var (q)')
+    close(st['E.E.encoder_k.norm.0.0.running_mean'], g['bn_k0_running_mean'], 1e-4, 'bn running mean (k)')

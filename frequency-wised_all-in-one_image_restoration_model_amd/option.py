@@ -1,5 +1,5 @@
 """`option.options` -- the import-time argparse singleton every reference script imports
-(`from option import options as opt`, /root/reference/option.py:3-115).  Flag names, types, defaults and the
+(`from option import options as opt`, reference option.py:3-115).  Flag names, types, defaults and the
 derived fields (batch_size, ckpt_path, encoder_dim, lr) follow the reference so that its train.py / test.py /
 plot_*.py drive this package unchanged.  Quirks kept on purpose: `type=bool` flags are truthy
 for any non-empty string; `contrast_loss_weight` stays None unless passed (the reference computes a default into

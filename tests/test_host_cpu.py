@@ -1,0 +1,83 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol include/fwair.h declares,
+the module tree reproduces the reference's state_dict schema, options keep the reference's names / defaults,
+and the product path refuses to run without the HIP device (no CPU fallback, no oracle import)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import VARIANTS, make_opt, schema
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'frequency-wised_all-in-one_image_restoration_model_amd')
+
+
+def test_library_exports_every_declared_symbol():
+    from fwair import lib
+    protos = lib.protos()
+    hdr = open(lib.HEADER_PATH).read()
+    declared = set(re.findall(r'\bint\s+(fw_\w+)\s*\(', hdr))
+    assert declared == set(protos), declared ^ set(protos)
+    assert len(declared) >= 40
+    nm = subprocess.run(['nm', '-D', '--defined-only', lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r' T (fw_\w+)', nm))
+    assert declared <= exported, declared - exported
+    assert lib.lib().fw_attn_lfs_table_elems() == 29696
+
+
+@pytest.mark.parametrize('variant', list(VARIANTS))
+def test_state_dict_schema_matches_reference(variant):
+    from net.model import AirNet
+    net = AirNet(make_opt(variant))
+    mine = [(k, list(v.shape), str(v.dtype).replace('torch.', '')) for k, v in net.state_dict().items()]
+    ref = [(k, list(s), d) for k, s, d in schema(variant)]
+    assert mine == ref
+    # key encoder starts as a copy of the query encoder and is frozen (moco.py:33-35)
+    for pq, pk in zip(net.E.E.encoder_q.parameters(), net.E.E.encoder_k.parameters()):
+        assert torch.equal(pq, pk) and not pk.requires_grad
+    mf = net.E.E.encoder_q.uformer.encoderlayer_0.blocks[0].attn_inter.mask_freq if variant != 'all3_origin' else None
+    if mf is not None:
+        L = make_opt(variant).L
+        assert mf.shape == (1, 1, 64 * L, 64 * L) and float(mf[0, 0, 0, 0]) == -100.0 and float(mf[0, 0, 0, 64]) == 0.0
+
+
+def test_no_cpu_fallback_and_no_oracle_import():
+    from fwair import lib
+    x = torch.zeros(8, 8)
+    with pytest.raises(RuntimeError, match='not on a HIP device'):
+        lib.call('fw_fill', x, 64, 0.0)                      # a CPU tensor is rejected before any launch
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(import|from)\s+(airnet_oracle|oracle|refshim)', src, re.M), f
+                assert '/root/reference' not in src, f     # nothing may read the reference at run time
+
+
+def test_unsupported_configurations_fail_loudly():
+    from net.model import AirNet
+    with pytest.raises(NotImplementedError):
+        AirNet(make_opt('all3', degradation_embedding_method=['residual']))        # the CLI default does not run in the reference either
+    with pytest.raises(NotImplementedError):
+        AirNet(make_opt('all3', encoder_type='ResNet', decoder_type='ResNet'))
+
+
+def test_option_defaults(monkeypatch):
+    monkeypatch.setattr(sys, 'argv', ['x', '--degradation_embedding_method', 'all_3_bands', '--de_type', 'denoising_25', 'denoising_25'])
+    sys.modules.pop('option', None)
+    from option import options as o
+    assert (o.batch_size, o.lr, o.encoder_dim, o.L, o.patch_size, o.encoder_msa_type) == (2, 2e-4, 256, 3, 128, 'freq')
+    assert o.contrast_loss_weight is None and o.default_contrast_loss_weight == 0.6
+    assert o.ckpt_path == 'output/tmp/ckpt/' and o.compute_dtype == 'fp32'
+    sys.modules.pop('option', None)
+
+
+def test_band_masks_equal_oracle():
+    import airnet_oracle as O
+    from fwair import lfs
+    for kind, size, n in (('frequency_decompose_1', 0.5, 128), ('frequency_decompose_1', 1.0, 64), ('frequency_decompose', 1 / 3., 64)):
+        for a, b in zip(lfs.band_masks_shifted(kind, size, n, n), O.band_masks(kind, size, n, n)):
+            assert torch.equal(a, b)

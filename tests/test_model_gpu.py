@@ -58,7 +58,10 @@ def test_train_step_fp32(variant):
     names = [str(n) for n in g['grad_names']]
     params = dict(net.named_parameters())
     norms = torch.tensor([params[n].grad.norm().item() for n in names])
-    rel = ((norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(1e-12))
+    # relative deviation, with a floor of 1e-6 x the largest norm: gradients that are ~0 by cancellation
+    # (e.g. 5e-11 for a 1x1 lambda-MLP weight) carry no relative information
+    floor = float(g['grad_norms'].max()) * 1e-6
+    rel = ((norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(floor))
     worst = int(rel.argmax())
     assert rel.max() < 5e-3, f'grad norm of {names[worst]}: {norms[worst]:.6e} vs {g["grad_norms"][worst]:.6e}'
     for key, val in g.items():

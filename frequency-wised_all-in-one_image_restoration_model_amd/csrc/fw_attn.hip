@@ -159,19 +159,18 @@ FW_DEV void band_filter(const f32x4 (&in)[4][4], f32x4 (&out)[4][4], char* scrA,
     {
         f32x4 tr[4][2], ti[4][2];
         zero_acc(tr); zero_acc(ti);
+#pragma unroll 1
         for (int c = 0; c < JC; ++c) {
-            uint4 a[4], bc[2], bs[2];
+            uint4 a[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) a[m] = frag_kc(scrA, LDP, m * 16, c);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                bc[n] = frag_kc(tab + (size_t)OFF_C2 * SZ, 64 * SZ, n * 16, c);
-                bs[n] = frag_kc(tab + (size_t)OFF_S2N * SZ, 64 * SZ, n * 16, c);
+                const uint4 bc = frag_kc(tab + (size_t)OFF_C2 * SZ, 64 * SZ, n * 16, c);
+                const uint4 bs = frag_kc(tab + (size_t)OFF_S2N * SZ, 64 * SZ, n * 16, c);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { mma_chunk<T>(tr[m][n], a[m], bc); mma_chunk<T>(ti[m][n], a[m], bs); }
             }
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) { mma_chunk<T>(tr[m][n], a[m], bc[n]); mma_chunk<T>(ti[m][n], a[m], bs[n]); }
         }
         __syncthreads();
 #pragma unroll
@@ -187,23 +186,22 @@ FW_DEV void band_filter(const f32x4 (&in)[4][4], f32x4 (&out)[4][4], char* scrA,
     {
         f32x4 xr[3][2], xi[3][2];
         zero_acc(xr); zero_acc(xi);
+#pragma unroll 1
         for (int c = 0; c < JC; ++c) {
-            uint4 ac[3], as[3], an[3], br[2], bi[2];
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                ac[m] = frag_kc(tab + (size_t)OFF_CU * SZ, 64 * SZ, m * 16, c);
-                as[m] = frag_kc(tab + (size_t)OFF_SU * SZ, 64 * SZ, m * 16, c);
-                an[m] = frag_kc(tab + (size_t)OFF_SUN * SZ, 64 * SZ, m * 16, c);
-            }
+            uint4 br[2], bi[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) { br[n] = frag_kc(scrB, LDP, n * 16, c); bi[n] = frag_kc(scrB + 32 * LDP, LDP, n * 16, c); }
 #pragma unroll
-            for (int m = 0; m < 3; ++m)
+            for (int m = 0; m < 3; ++m) {
+                const uint4 ac = frag_kc(tab + (size_t)OFF_CU * SZ, 64 * SZ, m * 16, c);
+                const uint4 as = frag_kc(tab + (size_t)OFF_SU * SZ, 64 * SZ, m * 16, c);
+                const uint4 an = frag_kc(tab + (size_t)OFF_SUN * SZ, 64 * SZ, m * 16, c);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    mma_chunk<T>(xr[m][n], ac[m], br[n]); mma_chunk<T>(xr[m][n], as[m], bi[n]);
-                    mma_chunk<T>(xi[m][n], ac[m], bi[n]); mma_chunk<T>(xi[m][n], an[m], br[n]);
+                    mma_chunk<T>(xr[m][n], ac, br[n]); mma_chunk<T>(xr[m][n], as, bi[n]);
+                    mma_chunk<T>(xi[m][n], ac, bi[n]); mma_chunk<T>(xi[m][n], an, br[n]);
                 }
+            }
         }
         __syncthreads();
         // zero the k padding u = 48..63 of Ys (two [32][64] panels)
@@ -228,23 +226,22 @@ FW_DEV void band_filter(const f32x4 (&in)[4][4], f32x4 (&out)[4][4], char* scrA,
     {
         f32x4 zr[2][4], zi[2][4];
         zero_acc(zr); zero_acc(zi);
+#pragma unroll 1
         for (int c = 0; c < JC; ++c) {
-            uint4 ar[2], ai[2], bc[4], bs[4], bn[4];
+            uint4 ar[2], ai[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) { ar[m] = frag_kc(scrA, LDP, m * 16, c); ai[m] = frag_kc(scrA + 32 * LDP, LDP, m * 16, c); }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                bc[n] = frag_kc(tab + (size_t)OFF_CH * SZ, 64 * SZ, n * 16, c);
-                bs[n] = frag_kc(tab + (size_t)OFF_SH * SZ, 64 * SZ, n * 16, c);
-                bn[n] = frag_kc(tab + (size_t)OFF_SHN * SZ, 64 * SZ, n * 16, c);
-            }
+                const uint4 bc = frag_kc(tab + (size_t)OFF_CH * SZ, 64 * SZ, n * 16, c);
+                const uint4 bs = frag_kc(tab + (size_t)OFF_SH * SZ, 64 * SZ, n * 16, c);
+                const uint4 bn = frag_kc(tab + (size_t)OFF_SHN * SZ, 64 * SZ, n * 16, c);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    mma_chunk<T>(zr[m][n], ar[m], bc[n]); mma_chunk<T>(zr[m][n], ai[m], bn[n]);
-                    mma_chunk<T>(zi[m][n], ai[m], bc[n]); mma_chunk<T>(zi[m][n], ar[m], bs[n]);
+                for (int m = 0; m < 2; ++m) {
+                    mma_chunk<T>(zr[m][n], ar[m], bc); mma_chunk<T>(zr[m][n], ai[m], bn);
+                    mma_chunk<T>(zi[m][n], ai[m], bc); mma_chunk<T>(zi[m][n], ar[m], bs);
                 }
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -258,19 +255,18 @@ FW_DEV void band_filter(const f32x4 (&in)[4][4], f32x4 (&out)[4][4], char* scrA,
     __syncthreads();
     // out^T[j][i] = sum_v Gc[j][v] Zr[i][v] + Gsn[j][v] Zi[i][v]
     zero_acc(out);
+#pragma unroll 1
     for (int c = 0; c < VC; ++c) {
-        uint4 ac[4], as[4], br[4], bi[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            ac[m] = frag_kc(tab + (size_t)OFF_GC * SZ, 32 * SZ, m * 16, c);
-            as[m] = frag_kc(tab + (size_t)OFF_GSN * SZ, 32 * SZ, m * 16, c);
-        }
+        uint4 br[4], bi[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) { br[n] = frag_kc(scrB, LDV, n * 16, c); bi[n] = frag_kc(scrB + 64 * LDV, LDV, n * 16, c); }
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m) {
+            const uint4 ac = frag_kc(tab + (size_t)OFF_GC * SZ, 32 * SZ, m * 16, c);
+            const uint4 as = frag_kc(tab + (size_t)OFF_GSN * SZ, 32 * SZ, m * 16, c);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) { mma_chunk<T>(out[m][n], ac[m], br[n]); mma_chunk<T>(out[m][n], as[m], bi[n]); }
+            for (int n = 0; n < 4; ++n) { mma_chunk<T>(out[m][n], ac, br[n]); mma_chunk<T>(out[m][n], as, bi[n]); }
+        }
     }
     __syncthreads();
 }
@@ -421,7 +417,8 @@ template <typename T, int D, int NKT, int LFS> struct SmemB {
     static constexpr int OFF_X = 4 * G::TILE_D, OFF_Y = OFF_X + SCR;
     static constexpr int OFF_DB = OFF_Y + SCR;                                                 // float [NKT][64][64]
     static constexpr int OFF_DI = OFF_DB + NKT * 64 * 64 * 4;                                  // float [64]
-    static constexpr int BYTES = OFF_DI + 256;
+    static constexpr int OFF_BIN = OFF_DI + 256;                                               // float [225] (+pad)
+    static constexpr int BYTES = OFF_BIN + 1024;
 };
 
 template <typename T, int D, int NKT, int LFS>
@@ -476,23 +473,24 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
             __syncthreads();
             // P^T[j][i] = exp(scale * K Q^T + bias + mask - lse_i)
             f32x4 p[4][4], dp[4][4];
-            zero_acc(p);
-            mma_tiles<T, 4, 4>(p, sK, G::LDR, 0, sQ, G::LDR, 0, G::KC);
             const float* tab = a.bias + (size_t)tabid * 225 * a.heads;
+            auto compute_p = [&]() {
+                asm volatile("" ::: "memory");            // do not keep the 64 gathered bias values live across the band filter
+                zero_acc(p);
+                mma_tiles<T, 4, 4>(p, sK, G::LDR, 0, sQ, G::LDR, 0, G::KC);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int i = it * 16 + (l & 15);
+                for (int it = 0; it < 4; ++it) {
+                    const int i = it * 16 + (l & 15);
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
+                    for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = jt * 16 + ((l >> 4) << 2) + r;
-                        p[jt][it][r] = __expf(p[jt][it][r] * a.scale + bias_mask(tab, a.heads, h, i, j, a.shift, last_y, last_x) - lse[it]);
-                    }
-            }
-            // dP'^T[j][i] = sum_d V[j][d] dO[i][d]
-            zero_acc(dp);
-            mma_tiles<T, 4, 4>(dp, sV, G::LDR, 0, sDO, G::LDR, 0, G::KC);
+                        for (int r = 0; r < 4; ++r) {
+                            const int j = jt * 16 + ((l >> 4) << 2) + r;
+                            p[jt][it][r] = __expf(p[jt][it][r] * a.scale + bias_mask(tab, a.heads, h, i, j, a.shift, last_y, last_x) - lse[it]);
+                        }
+                }
+            };
+            compute_p();
             float ca = 1.f, cc = 0.f;
             if constexpr (LFS >= 1) {
                 const float* cf = a.coef + ((size_t)b * a.heads + h) * 3;
@@ -543,12 +541,16 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
                 store_tile<T, D>(sY, dvp, a.ldd, nk, wy, wx, a.H, a.W, a.shift, h * D);
                 __syncthreads();
             }
+            // dP'^T[j][i] = sum_d V[j][d] dO[i][d]   (after dV: P' and its scratch are dead, keeps the live set small)
+            zero_acc(dp);
+            mma_tiles<T, 4, 4>(dp, sV, G::LDR, 0, sDO, G::LDR, 0, G::KC);
             if constexpr (LFS >= 1) {
                 // G^T = B1(dP')^T ; d(a,b,c) = (<dP',P>, sum dP', <G,P>) ; dP = a dP' + c G
                 float s1 = 0.f, s2 = 0.f, s3 = 0.f;
                 if constexpr (LFS == 2) {
                     f32x4 g[4][4];
                     band_filter<T>(dp, g, sX, sY, a.lfs);
+                    compute_p();                              // P is cheaper to rebuild (32 MFMA) than to keep live across the filter
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
@@ -609,8 +611,9 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
                 }
             __syncthreads();
             // dQ^T[d][i] += sum_j K[j][d] dS[i][j] ;  dK^T[d][j] = sum_i Q[i][d] dS[i][j]
-            f32x4 dk[G::DT][4];
+            f32x4 dk[G::DT][4], dql[G::DT][4];
             zero_acc(dk);
+            zero_acc(dql);
             for (int c = 0; c < G::JC; ++c) {
                 uint4 ak[G::DT], aq[G::DT], bx[4], by[4];
 #pragma unroll
@@ -620,8 +623,12 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int m = 0; m < G::DT; ++m)
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) { mma_chunk<T>(dq[m][n], ak[m], bx[n]); mma_chunk<T>(dk[m][n], aq[m], by[n]); }
+                    for (int n = 0; n < 4; ++n) { mma_chunk<T>(dql[m][n], ak[m], bx[n]); mma_chunk<T>(dk[m][n], aq[m], by[n]); }
             }
+#pragma unroll
+            for (int m = 0; m < G::DT; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) dq[m][n] += dql[m][n];
             __syncthreads();
 #pragma unroll
             for (int m = 0; m < G::DT; ++m)
@@ -640,16 +647,21 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
         store_tile<T, D>(sY, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D);
         __syncthreads();
     }
-    // flush the bias-gradient accumulators into the parameter layout [table][225][heads]
-    __syncthreads();
+    // flush the bias-gradient accumulators: fold the 64x64 pairs into the 225 relative positions on chip, then one
+    // atomic per bin into the parameter layout [table][225][heads] (all workgroups of a head hit the same 225 words)
+    float* bins = reinterpret_cast<float*>(smem + S::OFF_BIN);
     for (int kt = 0; kt < NKT; ++kt) {
-        const int lk = a.mode == 0 ? lq : other_band(lq, kt);
-        float* dst = a.dbias + (size_t)(lq * a.L + lk) * 225 * a.heads;
+        __syncthreads();
+        for (int idx = l; idx < 225; idx += 64) bins[idx] = 0.f;
+        __syncthreads();
         for (int idx = l; idx < 4096; idx += 64) {
             const int i = idx >> 6, j = idx & 63;
-            const int dy = (i >> 3) - (j >> 3) + 7, dx = (i & 7) - (j & 7) + 7;
-            atomicAdd(dst + (dy * 15 + dx) * a.heads + h, sDB[kt * 4096 + idx]);
+            atomicAdd(&bins[((i >> 3) - (j >> 3) + 7) * 15 + (i & 7) - (j & 7) + 7], sDB[kt * 4096 + idx]);
         }
+        __syncthreads();
+        const int lk = a.mode == 0 ? lq : other_band(lq, kt);
+        float* dst = a.dbias + (size_t)(lq * a.L + lk) * 225 * a.heads;
+        for (int idx = l; idx < 225; idx += 64) atomicAdd(dst + idx * a.heads + h, bins[idx]);
     }
 }
 

@@ -75,11 +75,14 @@ __global__ void permute3_kernel(const TI* __restrict__ in, TO* __restrict__ out,
 }
 
 // ------------------------------------------------------------------------------------------------
-// LeFF: h2 = dwconv3x3(GELU(h1)) + bias          (net/utils/leff.py:104-111)
+// LeFF depthwise 3x3 (net/utils/leff.py:104-111).  Pre- and post-activation tensors are both kept
+// (h = pre, g = GELU(h)) so no erf is ever recomputed per tap:
+//   fwd : h2 = dwconv3x3(g1) + bias ;  g2 = GELU(h2)
+//   bwd : dh1 = GELU'(h1) * convT(dh2, w) ;  dw[c][tap] += sum_t g1[t+tap] dh2[t] ;  dbias[c] += sum_t dh2[t]
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void dwconv_fwd_kernel(const T* __restrict__ h1, long ld1, const float* __restrict__ w, const float* __restrict__ bias,
-                                  T* __restrict__ h2, long ld2, int B, int H, int W, int C) {
+__global__ void dwconv_fwd_kernel(const T* __restrict__ g1, long ld1, const float* __restrict__ w, const float* __restrict__ bias,
+                                  T* __restrict__ h2, T* __restrict__ g2, long ld2, int B, int H, int W, int C) {
     constexpr int E = TT<T>::E16;
     const int nv = C / E;
     const long total = (long)B * H * W * nv;
@@ -87,9 +90,13 @@ __global__ void dwconv_fwd_kernel(const T* __restrict__ h1, long ld1, const floa
         const int v = (int)(i % nv); const long tok = i / nv;
         const int x = (int)(tok % W); const int y = (int)((tok / W) % H); const long b = tok / ((long)W * H);
         const int c0 = v * E;
-        float acc[E];
+        float acc[E], wr[E][9];
 #pragma unroll
-        for (int e = 0; e < E; ++e) acc[e] = bias[c0 + e];
+        for (int e = 0; e < E; ++e) {
+            acc[e] = bias[c0 + e];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wr[e][t] = w[(c0 + e) * 9 + t];
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int yy = y + ky - 1;
@@ -99,20 +106,23 @@ __global__ void dwconv_fwd_kernel(const T* __restrict__ h1, long ld1, const floa
                 const int xx = x + kx - 1;
                 if (xx < 0 || xx >= W) continue;
                 float f[E];
-                ldvec<T>(h1 + ((b * H + yy) * W + xx) * ld1 + c0, f);
+                ldvec<T>(g1 + ((b * H + yy) * W + xx) * ld1 + c0, f);
 #pragma unroll
-                for (int e = 0; e < E; ++e) acc[e] += gelu_f(f[e]) * w[(c0 + e) * 9 + ky * 3 + kx];
+                for (int e = 0; e < E; ++e) acc[e] += f[e] * wr[e][ky * 3 + kx];
             }
         }
         stvec<T>(h2 + tok * ld2 + c0, acc);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = gelu_f(acc[e]);
+        stvec<T>(g2 + tok * ld2 + c0, acc);
     }
 }
 
-// dh1 = GELU'(h1) * convT(dh2, w);  dw[c][tap] += sum_t GELU(h1[t+tap]) dh2[t];  dbias[c] += sum_t dh2[t]
-// thread = (token stripe, channel vector); STRIPE consecutive tokens per thread.
+// thread = (token stripe, channel vector); STRIPE consecutive tokens per thread, partial weight sums in registers.
 template <typename T, int STRIPE>
-__global__ void dwconv_bwd_kernel(const T* __restrict__ dh2, long ldg, const T* __restrict__ h1, long ld1, const float* __restrict__ w,
-                                  T* __restrict__ dh1, long ldo, float* __restrict__ dw, float* __restrict__ dbias, int B, int H, int W, int C) {
+__global__ void dwconv_bwd_kernel(const T* __restrict__ dh2, long ldg, const T* __restrict__ g1, const T* __restrict__ h1, long ld1,
+                                  const float* __restrict__ w, T* __restrict__ dh1, long ldo, float* __restrict__ dw, float* __restrict__ dbias,
+                                  int B, int H, int W, int C) {
     constexpr int E = TT<T>::E16;
     const int nv = C / E;
     const long ntok = (long)B * H * W;
@@ -138,16 +148,14 @@ __global__ void dwconv_bwd_kernel(const T* __restrict__ dh2, long ldg, const T* 
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    // weight gradient: tap (ky,kx) pairs output t with input t + (ky-1, kx-1)
-                    const int yy = y + ky - 1, xx = x + kx - 1;
+                    const int yy = y + ky - 1, xx = x + kx - 1;          // weight gradient: output t x input t + (ky-1, kx-1)
                     if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
                         float f[E];
-                        ldvec<T>(h1 + ((b * H + yy) * W + xx) * ld1 + c0, f);
+                        ldvec<T>(g1 + ((b * H + yy) * W + xx) * ld1 + c0, f);
 #pragma unroll
-                        for (int e = 0; e < E; ++e) gw[e][ky * 3 + kx] += gelu_f(f[e]) * g0[e];
+                        for (int e = 0; e < E; ++e) gw[e][ky * 3 + kx] += f[e] * g0[e];
                     }
-                    // data gradient: input t receives w[tap] * dh2[t - (ky-1, kx-1)]
-                    const int yo = y - ky + 1, xo = x - kx + 1;
+                    const int yo = y - ky + 1, xo = x - kx + 1;          // data gradient: input t <- w[tap] * dh2[t - (ky-1, kx-1)]
                     if (yo >= 0 && yo < H && xo >= 0 && xo < W) {
                         float f[E];
                         ldvec<T>(dh2 + ((b * H + yo) * W + xo) * ldg + c0, f);
@@ -522,23 +530,25 @@ extern "C" int fw_permute3(int in_dtype, int out_dtype, const void* in, void* ou
     if (in_dtype == 1 && out_dtype == 0) LAUNCH((permute3_kernel<bf16raw, float>), n, (const bf16raw*)in, (float*)out, d0, d1, d2, s0, s1, s2, accumulate);
     return -1;
 }
-extern "C" int fw_dwconv_fwd(int dtype, const void* h1, long ld1, const float* w, const float* bias, void* h2, long ld2, int B,
-                             int H, int W, int C, void* stream) {
+extern "C" int fw_dwconv_fwd(int dtype, const void* g1, long ld1, const float* w, const float* bias, void* h2, void* g2, long ld2,
+                             int B, int H, int W, int C, void* stream) {
     const int e = dtype == FW_DT_BF16 ? 8 : 4;
-    FW_CHECK_ARG(h1 && w && bias && h2 && C % e == 0 && ld1 % e == 0 && ld2 % e == 0);
+    FW_CHECK_ARG(g1 && w && bias && h2 && g2 && C % e == 0 && ld1 % e == 0 && ld2 % e == 0);
     const long n = (long)B * H * W * (C / e);
-    if (dtype == FW_DT_BF16) LAUNCH((dwconv_fwd_kernel<bf16raw>), n, (const bf16raw*)h1, ld1, w, bias, (bf16raw*)h2, ld2, B, H, W, C);
-    LAUNCH((dwconv_fwd_kernel<float>), n, (const float*)h1, ld1, w, bias, (float*)h2, ld2, B, H, W, C);
+    if (dtype == FW_DT_BF16) LAUNCH((dwconv_fwd_kernel<bf16raw>), n, (const bf16raw*)g1, ld1, w, bias, (bf16raw*)h2, (bf16raw*)g2, ld2, B, H, W, C);
+    LAUNCH((dwconv_fwd_kernel<float>), n, (const float*)g1, ld1, w, bias, (float*)h2, (float*)g2, ld2, B, H, W, C);
 }
-extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* h1, long ld1, const float* w, void* dh1, long ldo,
-                             float* dw, float* dbias, int B, int H, int W, int C, void* stream) {
+extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g1, const void* h1, long ld1, const float* w, void* dh1,
+                             long ldo, float* dw, float* dbias, int B, int H, int W, int C, void* stream) {
     const int e = dtype == FW_DT_BF16 ? 8 : 4;
-    FW_CHECK_ARG(dh2 && h1 && w && dh1 && dw && dbias && C % e == 0 && ld1 % e == 0 && ldg % e == 0 && ldo % e == 0);
-    constexpr int STRIPE = 64;
+    FW_CHECK_ARG(dh2 && g1 && h1 && w && dh1 && dw && dbias && C % e == 0 && ld1 % e == 0 && ldg % e == 0 && ldo % e == 0);
+    constexpr int STRIPE = 32;
     const long n = (((long)B * H * W + STRIPE - 1) / STRIPE) * (C / e);
     if (dtype == FW_DT_BF16)
-        LAUNCH((dwconv_bwd_kernel<bf16raw, STRIPE>), n, (const bf16raw*)dh2, ldg, (const bf16raw*)h1, ld1, w, (bf16raw*)dh1, ldo, dw, dbias, B, H, W, C);
-    LAUNCH((dwconv_bwd_kernel<float, STRIPE>), n, (const float*)dh2, ldg, (const float*)h1, ld1, w, (float*)dh1, ldo, dw, dbias, B, H, W, C);
+        LAUNCH((dwconv_bwd_kernel<bf16raw, STRIPE>), n, (const bf16raw*)dh2, ldg, (const bf16raw*)g1, (const bf16raw*)h1, ld1, w, (bf16raw*)dh1,
+               ldo, dw, dbias, B, H, W, C);
+    LAUNCH((dwconv_bwd_kernel<float, STRIPE>), n, (const float*)dh2, ldg, (const float*)g1, (const float*)h1, ld1, w, (float*)dh1, ldo, dw, dbias,
+           B, H, W, C);
 }
 extern "C" int fw_im2col4(int dtype, const float* x, long ldx, void* col, int B, int H, int W, int C, void* stream) {
     FW_CHECK_ARG(x && col && C % 4 == 0 && ldx % 4 == 0 && H % 2 == 0 && W % 2 == 0);

@@ -32,10 +32,15 @@ struct GemmArgs {
     int out_f32;                        // C is float (else T)
     int accumulate;                     // 0 store, 1 atomicAdd (f32 C only)
     int splitk; int kper;               // K range per z-slice (multiple of the K step)
+    char* C2; long ldc2;                // optional second output GELU(v), type T
+    float* xsum;                        // optional: xsum[m] += sum_k X(m,k) (x_trans only; the bias gradient of a dW GEMM)
     float alpha;
 };
 
-constexpr int LDS_ROW = 144;            // 128 B of K + 16 B pad
+constexpr int LDS_ROW = 128;            // 128 B of K per row, XOR-swizzled in 16-byte slots (no padding)
+// slot swizzle: spreads both the row-strided fragment reads (rows r..r+15, same slot) and the 8-row-strided
+// transposed staging writes (rows 8*ib+e) over the 8 slots of a row
+FW_DEV int swz(int row) { return ((row ^ (row >> 3)) & 7) << 4; }
 constexpr int BM = 128;
 
 template <typename T> FW_DEV uint4 apply_gelu16(const uint4& v) {
@@ -78,7 +83,8 @@ struct StageDirect {
 #pragma unroll
         for (int t = 0; t < NL; ++t) {
             const int cid = tid + 256 * t;
-            *reinterpret_cast<uint4*>(tile + (cid >> 3) * LDS_ROW + (cid & 7) * 16) = r[t];
+            const int row = cid >> 3;
+            *reinterpret_cast<uint4*>(tile + row * LDS_ROW + (((cid & 7) * 16) ^ swz(row))) = r[t];
         }
     }
 };
@@ -105,18 +111,27 @@ struct StageTrans {
             r[kk] = v;
         }
     }
+    FW_MEM void accum(float (&s)[TT<T>::E16]) const {        // column sums of the staged block (bias gradient)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float f[TT<T>::E16];
+            unpack16<T>(r[kk], f);
+#pragma unroll
+            for (int e = 0; e < TT<T>::E16; ++e) s[e] += f[e];
+        }
+    }
     FW_MEM void store(char* tile) const {
         const int tid = threadIdx.x;
         if (tid >= NTHR) return;
         const int ib = tid % IB, kb = tid / IB;
         if constexpr (sizeof(T) == 4) {
-            char* p = tile + (ib * 4) * LDS_ROW + kb * 16;
-            *reinterpret_cast<uint4*>(p) = make_uint4(r[0].x, r[1].x, r[2].x, r[3].x);
-            *reinterpret_cast<uint4*>(p + LDS_ROW) = make_uint4(r[0].y, r[1].y, r[2].y, r[3].y);
-            *reinterpret_cast<uint4*>(p + 2 * LDS_ROW) = make_uint4(r[0].z, r[1].z, r[2].z, r[3].z);
-            *reinterpret_cast<uint4*>(p + 3 * LDS_ROW) = make_uint4(r[0].w, r[1].w, r[2].w, r[3].w);
+            const int r0 = ib * 4, cb = kb * 16;
+            *reinterpret_cast<uint4*>(tile + (r0 + 0) * LDS_ROW + (cb ^ swz(r0 + 0))) = make_uint4(r[0].x, r[1].x, r[2].x, r[3].x);
+            *reinterpret_cast<uint4*>(tile + (r0 + 1) * LDS_ROW + (cb ^ swz(r0 + 1))) = make_uint4(r[0].y, r[1].y, r[2].y, r[3].y);
+            *reinterpret_cast<uint4*>(tile + (r0 + 2) * LDS_ROW + (cb ^ swz(r0 + 2))) = make_uint4(r[0].z, r[1].z, r[2].z, r[3].z);
+            *reinterpret_cast<uint4*>(tile + (r0 + 3) * LDS_ROW + (cb ^ swz(r0 + 3))) = make_uint4(r[0].w, r[1].w, r[2].w, r[3].w);
         } else {
-            char* p = tile + (ib * 8) * LDS_ROW + kb * 8;
+            const int r0 = ib * 8, cb = kb * 8;
             const unsigned w0[4] = {r[0].x, r[0].y, r[0].z, r[0].w};
             const unsigned w1[4] = {r[1].x, r[1].y, r[1].z, r[1].w};
             const unsigned w2[4] = {r[2].x, r[2].y, r[2].z, r[2].w};
@@ -128,15 +143,18 @@ struct StageTrans {
                                       __builtin_amdgcn_perm(w3[d], w2[d], 0x05040100u));
                 uint2 hi = make_uint2(__builtin_amdgcn_perm(w1[d], w0[d], 0x07060302u),
                                       __builtin_amdgcn_perm(w3[d], w2[d], 0x07060302u));
-                *reinterpret_cast<uint2*>(p + (2 * d) * LDS_ROW) = lo;
-                *reinterpret_cast<uint2*>(p + (2 * d + 1) * LDS_ROW) = hi;
+                *reinterpret_cast<uint2*>(tile + (r0 + 2 * d) * LDS_ROW + (cb ^ swz(r0 + 2 * d))) = lo;
+                *reinterpret_cast<uint2*>(tile + (r0 + 2 * d + 1) * LDS_ROW + (cb ^ swz(r0 + 2 * d + 1))) = hi;
             }
         }
     }
 };
 
+template <typename T, int ROWS> struct StageDirectAcc : StageDirect<T, ROWS> {
+    FW_MEM void accum(float (&)[TT<T>::E16]) const {}
+};
 template <typename T, int ROWS, bool TRANS> struct Stage;
-template <typename T, int ROWS> struct Stage<T, ROWS, false> : StageDirect<T, ROWS> {
+template <typename T, int ROWS> struct Stage<T, ROWS, false> : StageDirectAcc<T, ROWS> {
     FW_MEM void fetch(const char* base, long ld, int row0, int rows_total, int k0, int k_end, int op) {
         this->load(base, ld, row0, rows_total, k0 * TT<T>::SZ, k_end * TT<T>::SZ, op);
     }
@@ -146,6 +164,12 @@ template <typename T, int ROWS> struct Stage<T, ROWS, true> : StageTrans<T, ROWS
         this->load(base, ld, row0, rows_total, k0, k_end, op);
     }
 };
+
+FW_DEV uint4 frag_sw(const char* tile, int row0, int chunk) {
+    const int l = lane_id();
+    const int row = row0 + (l & 15);
+    return *reinterpret_cast<const uint4*>(tile + row * LDS_ROW + ((chunk * 64 + ((l >> 4) << 4)) ^ swz(row)));
+}
 
 template <typename T, int BN, bool XT, bool WT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
@@ -170,8 +194,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 
     Stage<T, BM, XT> sx;
     Stage<T, BN, WT> sw;
+    float xsum[TT<T>::E16];
+#pragma unroll
+    for (int e = 0; e < TT<T>::E16; ++e) xsum[e] = 0.f;
+    const bool do_xsum = XT && a.xsum != nullptr && blockIdx.y == 0;
     if (nsteps > 0) {
         sx.fetch(a.X, a.ldx, m_blk, a.M, k_begin, k_end, a.x_op);
+        if (do_xsum) sx.accum(xsum);
         sw.fetch(a.W, a.ldw, n_blk, a.N, k_begin, k_end, a.w_op);
         sx.store(xs(0));
         sw.store(ws(0));
@@ -182,8 +211,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         if (s + 1 < nsteps) {
             sx.fetch(a.X, a.ldx, m_blk, a.M, k_begin + (s + 1) * KT, k_end, a.x_op);
             sw.fetch(a.W, a.ldw, n_blk, a.N, k_begin + (s + 1) * KT, k_end, a.w_op);
+            if (do_xsum) sx.accum(xsum);
         }
-        mma_tiles<T, 4, WM>(acc, ws(cur), LDS_ROW, wn0, xs(cur), LDS_ROW, wm0, 2);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint4 af[4], bfr[WM];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = frag_sw(ws(cur), wn0 + 16 * m, c);
+#pragma unroll
+            for (int n = 0; n < WM; ++n) bfr[n] = frag_sw(xs(cur), wm0 + 16 * n, c);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < WM; ++n) mma_chunk<T>(acc[m][n], af[m], bfr[n]);
+        }
         if (s + 1 < nsteps) {
             sx.store(xs(cur ^ 1));
             sw.store(ws(cur ^ 1));
@@ -191,6 +232,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         __syncthreads();
     }
 
+    if constexpr (XT) {
+        if (do_xsum) {
+            constexpr int E = TT<T>::E16, IB = BM / E;
+            if ((int)threadIdx.x < IB * ((128 / TT<T>::SZ) / 4)) {
+                const int ib = threadIdx.x % IB;
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (m_blk + ib * E + e < a.M) atomicAdd(a.xsum + m_blk + ib * E + e, xsum[e]);
+            }
+        }
+    }
     // ---- epilogue: lane holds C[m][n0..n0+3], m = col of the MFMA tile, n = rows -------------
     const int l = lane_id();
 #pragma unroll
@@ -229,6 +281,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
                 const f32x4 rr = *reinterpret_cast<const f32x4*>(a.residual + (long)m * a.ldr + n0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += rr[r];
+            }
+            if (a.C2) {
+                T* c2 = reinterpret_cast<T*>(a.C2) + (long)m * a.ldc2 + n0;
+                const float g0 = gelu_f(v[0]), g1 = gelu_f(v[1]), g2 = gelu_f(v[2]), g3 = gelu_f(v[3]);
+                if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(c2) = f32x4{g0, g1, g2, g3};
+                else *reinterpret_cast<uint2*>(c2) = make_uint2(pack_bf2(g0, g1), pack_bf2(g2, g3));
             }
             if (a.out_f32) {
                 float* cp = reinterpret_cast<float*>(a.C) + (long)m * a.ldc + n0;
@@ -279,7 +337,7 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
                        int w_trans, int w_op, void* C, long ldc, int out_f32, int accumulate, int M, int N,
                        int K, float alpha, const float* bias, int act, float slope, const void* aux,
                        long ldaux, const float* rowscale, int rows_per_scale, const float* residual,
-                       long ldr, int splitk, void* stream) {
+                       long ldr, int splitk, void* C2, long ldc2, float* xsum, void* stream) {
     const int sz = dtype == FW_DT_BF16 ? 2 : 4;
     const int e16 = 16 / sz;
     FW_CHECK_ARG(dtype == FW_DT_F32 || dtype == FW_DT_BF16);
@@ -306,6 +364,9 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
     a.out_f32 = (out_f32 || dtype == FW_DT_F32) ? 1 : 0;
     a.accumulate = accumulate;
     a.splitk = splitk;
+    a.C2 = (char*)C2; a.ldc2 = ldc2; a.xsum = xsum;
+    FW_CHECK_ARG(!xsum || x_trans);
+    FW_CHECK_ARG(!C2 || (((uintptr_t)C2 & (4 * sz - 1)) == 0 && ldc2 % 4 == 0));
     a.kper = fw_cdiv(fw_cdiv(K, kt), splitk) * kt;
     a.alpha = alpha;
     hipStream_t st = (hipStream_t)stream;

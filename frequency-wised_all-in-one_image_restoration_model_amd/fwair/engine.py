@@ -55,30 +55,33 @@ def train_loss(restored, clean, logits, w, gscale=1.0):
 # ---------------------------------------------------------------------------------------------------------------
 # flat storage
 # ---------------------------------------------------------------------------------------------------------------
+def _layout(params):
+    """Element offset of every parameter in a flat buffer; each starts 16-byte aligned (vector loads of biases, GEMM operands)."""
+    offs, o = [], 0
+    for p in params:
+        offs.append(o)
+        o += (p.numel() + 3) // 4 * 4
+    return offs, o
+
+
 def flatten_parameters(params, device=None):
-    """Re-home `params` into one contiguous f32 buffer (each parameter becomes a view).  Returns the flat tensor."""
+    """Re-home `params` into one contiguous, zero-padded f32 buffer (each parameter becomes a 16-byte aligned view)."""
     params = list(params)
     device = device or params[0].device
-    n = sum(p.numel() for p in params)
-    pad = (-n) % 4
-    flat = torch.empty(n + pad, dtype=torch.float32, device=device)
-    if pad:
-        flat[n:].zero_()
-    o = 0
+    offs, n = _layout(params)
+    flat = torch.zeros(n, dtype=torch.float32, device=device)
     with torch.no_grad():
-        for p in params:
+        for p, o in zip(params, offs):
             v = flat[o:o + p.numel()].view_as(p)
             v.copy_(p.data)
             p.data = v
-            o += p.numel()
     return flat
 
 
 def attach_flat_grads(params, flat_g):
-    o = 0
-    for p in params:
+    offs, _ = _layout(params)
+    for p, o in zip(params, offs):
         p.grad = flat_g[o:o + p.numel()].view_as(p)
-        o += p.numel()
 
 
 class GradAllReducer:
@@ -130,8 +133,9 @@ class TrainEngine:
         assert dev.type == 'cuda', 'TrainEngine needs the HIP device'
         self.flat_p = flatten_parameters(self.trainable, dev)
         self.flat_k = flatten_parameters(enc_k, dev)
-        self.n_enc = sum(p.numel() for p in enc_q)
-        self.n = sum(p.numel() for p in self.trainable)
+        self.n_enc = _layout(enc_q)[1]                       # padded extents: the two encoder buffers share one layout
+        self.n = self.flat_p.numel()
+        assert self.flat_k.numel() == self.n_enc
         self.flat_g = torch.zeros_like(self.flat_p)
         attach_flat_grads(self.trainable, self.flat_g)
         self.m = torch.zeros_like(self.flat_p)
@@ -143,6 +147,7 @@ class TrainEngine:
             dist.broadcast(self.flat_p, src=0)             # identical replicas at start
             dist.broadcast(self.flat_k, src=0)
         Fn.config.shadow_epoch += 1
+        Fn.config.direct_grads = True                     # kernels add into the flat .grad views; autograd sees None
         self._graph = None
         self._static = None
         self.last = None

@@ -16,6 +16,7 @@ from .lib import call, dt
 class config:
     compute_dtype = torch.float32       # torch.float32 | torch.bfloat16
     shadow_epoch = 0                    # bumped by the engine after a fused optimizer step
+    direct_grads = False                # engine mode: kernels accumulate straight into the (pre-zeroed) flat .grad views
 
 
 def act_empty(rows, cols, dtype, device):
@@ -82,18 +83,30 @@ def _zeros(shape, device):
     return torch.zeros(shape, dtype=torch.float32, device=device)
 
 
-def _wgrad(g, x, n, k, m, x_op=0):
-    """dW[n][k] = sum_m g[m][n] * op(x)[m][k]  (both operands reduction-major)."""
-    dw = _zeros((n, k), g.device)
-    ops.gemm(g, x, n, k, m, x_trans=True, w_trans=True, w_op=x_op, out=dw, accumulate=True,
-             splitk=ops.pick_splitk(n, k, m, g.dtype))
-    return dw
+def _grad_target(param, shape=None):
+    """(buffer to accumulate into, value to hand back to autograd).  In engine mode the kernels add straight into the
+    parameter's flat .grad view and autograd gets None (no zero-fill, no extra add kernel)."""
+    if config.direct_grads and param is not None and param.grad is not None:
+        g = param.grad
+        return (g if shape is None else g.view(shape)), None
+    z = _zeros(param.shape if shape is None else shape, param.device)
+    return z, z
 
 
-def _bgrad(g, n):
-    db = _zeros((n,), g.device)
+def _wgrad(g, x, n, k, m, weight, bias=None):
+    """dW[n][k] += sum_m g[m][n] x[m][k]  (both operands reduction-major); db[n] += sum_m g[m][n] falls out of the
+    same pass (xsum).  Returns the autograd values (dW, db)."""
+    dw, rw = _grad_target(weight, (n, k))
+    db, rb = _grad_target(bias) if bias is not None else (None, None)
+    ops.gemm(g, x, n, k, m, x_trans=True, w_trans=True, out=dw, accumulate=True,
+             splitk=ops.pick_splitk(n, k, m, g.dtype), xsum=db)
+    return (rw.view_as(weight) if rw is not None else None), rb
+
+
+def _bgrad(g, bias):
+    db, rb = _grad_target(bias)
     ops.colsum(g, db)
-    return db
+    return rb
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -108,26 +121,31 @@ class LayerNormFn(torch.autograd.Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         call('fw_layernorm_fwd', dt(y.dtype), x, x.stride(0), gamma, beta, y, y.stride(0), mean, rstd, rows, C, 1e-5)
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.beta = beta
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         dy = aligned(dy)
-        dg, db = _zeros(gamma.shape, x.device), _zeros(gamma.shape, x.device)
+        beta = ctx.beta
+        dg, rg = _grad_target(gamma)
+        db, rb = _grad_target(beta)
         dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db)
-        return dx, dg, db
+        return dx, rg, rb
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # Linear : T -> T | f32 (+ residual stream, DropPath row scale, GELU on the input, LeakyReLU on the output)
 # ---------------------------------------------------------------------------------------------------------------
 class LinearFn(torch.autograd.Function):
-    """y = [residual +] rowscale * (op(x) W^T + b).   x: T [M, K];  W: f32 parameter [N, K].
-    x_gelu: op = GELU (LeFF: the stored tensors are pre-activations).  out_f32: y is the f32 stream."""
+    """y = [residual +] rowscale * (x W^T + b).   x: T [M, K];  W: f32 parameter [N, K].
+    gelu_out: also return g = GELU(y) (non-differentiable twin; LeFF keeps pre- and post-activations).
+    x_pre: x is GELU(x_pre) computed upstream; the input gradient is routed to x_pre (times GELU'(x_pre)).
+    out_f32: y is f32."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, rowscale, rows_per_scale, x_gelu, out_f32):
+    def forward(ctx, x, weight, bias, residual, rowscale, rows_per_scale, x_pre, gelu_out, out_f32):
         M, K = x.shape
         N = weight.shape[0]
         w = shadow(weight)
@@ -135,16 +153,22 @@ class LinearFn(torch.autograd.Function):
             y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         else:
             y = act_empty(M, N, x.dtype, x.device)
-        ops.gemm(x, w, M, N, K, x_op=int(x_gelu), out=y, bias=bias, rowscale=rowscale, rows_per_scale=rows_per_scale,
-                 residual=residual)
-        ctx.save_for_backward(x, weight, rowscale)
-        ctx.cfg = (rows_per_scale, x_gelu, residual is not None, bias is not None)
+        g = act_empty(M, N, x.dtype, x.device) if gelu_out else None
+        ops.gemm(x, w, M, N, K, out=y, bias=bias, rowscale=rowscale, rows_per_scale=rows_per_scale, residual=residual,
+                 out_gelu=g)
+        ctx.save_for_backward(x, weight, rowscale, x_pre)
+        ctx.bias = bias
+        ctx.cfg = (rows_per_scale, residual is not None)
+        if gelu_out:
+            ctx.mark_non_differentiable(g)
+            return y, g
         return y
 
     @staticmethod
-    def backward(ctx, dy):
-        x, weight, rowscale = ctx.saved_tensors
-        rows_per_scale, x_gelu, has_res, has_bias = ctx.cfg
+    def backward(ctx, dy, *_):
+        x, weight, rowscale, x_pre = ctx.saved_tensors
+        rows_per_scale, has_res = ctx.cfg
+        bias = ctx.bias
         M, K = x.shape
         N = weight.shape[0]
         if dy.dtype == torch.float32 and x.dtype != torch.float32 or rowscale is not None:
@@ -152,17 +176,20 @@ class LinearFn(torch.autograd.Function):
             call('fw_cast_rows', dt(x.dtype), dy, dy.stride(0), g, g.stride(0), M, N, rowscale, rows_per_scale)
         else:
             g = aligned(dy)
-        dw = _wgrad(g, x, N, K, M, x_op=int(x_gelu)).view_as(weight) if ctx.needs_input_grad[1] else None
-        db = _bgrad(g, N) if has_bias and ctx.needs_input_grad[2] else None
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = act_empty(M, K, x.dtype, x.device)
-            ops.gemm(g, shadow(weight), M, K, N, w_trans=True, out=dx, act=2 if x_gelu else 0, aux=x if x_gelu else None)
-        return dx, dw, db, (dy if has_res else None), None, None, None, None
+        dw, db = _wgrad(g, x, N, K, M, weight, bias)
+        dx = dpre = None
+        if ctx.needs_input_grad[0] or (x_pre is not None and ctx.needs_input_grad[6]):
+            d = act_empty(M, K, x.dtype, x.device)
+            ops.gemm(g, shadow(weight), M, K, N, w_trans=True, out=d, act=2 if x_pre is not None else 0, aux=x_pre)
+            if x_pre is not None:
+                dpre = d
+            else:
+                dx = d
+        return dx, dw, db, (dy if has_res else None), None, None, dpre, None, None
 
 
-def linear(x, weight, bias=None, residual=None, rowscale=None, rows_per_scale=1, x_gelu=False, out_f32=False):
-    return LinearFn.apply(x, weight, bias, residual, rowscale, rows_per_scale, x_gelu, out_f32)
+def linear(x, weight, bias=None, residual=None, rowscale=None, rows_per_scale=1, x_pre=None, gelu_out=False, out_f32=False):
+    return LinearFn.apply(x, weight, bias, residual, rowscale, rows_per_scale, x_pre, gelu_out, out_f32)
 
 
 class QKVFn(torch.autograd.Function):
@@ -178,6 +205,7 @@ class QKVFn(torch.autograd.Function):
         ops.gemm(x, shadow(wq), M, C, K, out=buf[:, :C], bias=bq)
         ops.gemm(x, shadow(wkv), M, 2 * C, K, out=buf[:, Cp:], bias=bkv)
         ctx.save_for_backward(x, wq, wkv)
+        ctx.bq, ctx.bkv = bq, bkv
         return buf
 
     @staticmethod
@@ -188,9 +216,8 @@ class QKVFn(torch.autograd.Function):
         Cp = (C + 7) // 8 * 8
         dbuf = aligned(dbuf)
         dq, dkv = dbuf[:, :C], dbuf[:, Cp:]
-        dwq = _wgrad(dq, x, C, K, M)
-        dwkv = _wgrad(dkv, x, 2 * C, K, M)
-        dbq, dbkv = _bgrad(dq, C), _bgrad(dkv, 2 * C)
+        dwq, dbq = _wgrad(dq, x, C, K, M, wq, ctx.bq)
+        dwkv, dbkv = _wgrad(dkv, x, 2 * C, K, M, wkv, ctx.bkv)
         tmp = torch.empty((M, K), dtype=torch.float32, device=x.device)
         ops.gemm(dq, shadow(wq), M, K, C, w_trans=True, out=tmp)
         dx = act_empty(M, K, x.dtype, x.device)
@@ -247,25 +274,32 @@ class WindowAttnFn(torch.autograd.Function):
 # LeFF depthwise conv (input and output are pre-activations; GELU is applied on load by the consumers)
 # ---------------------------------------------------------------------------------------------------------------
 class DwConvFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, h1, weight, bias, B, H, W):
-        C = h1.shape[1]
-        h2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
-        call('fw_dwconv_fwd', dt(h1.dtype), h1, h1.stride(0), weight, bias, h2, h2.stride(0), B, H, W, C)
-        ctx.save_for_backward(h1, weight)
-        ctx.geo = (B, H, W)
-        return h2
+    """(h1, g1 = GELU(h1)) -> (h2, g2 = GELU(h2)).  Gradients flow through the pre-activations only: backward receives
+    d h2 (LinearFn routes it there via x_pre) and returns d h1."""
 
     @staticmethod
-    def backward(ctx, dh2):
-        h1, weight = ctx.saved_tensors
+    def forward(ctx, h1, g1, weight, bias, B, H, W):
+        C = h1.shape[1]
+        h2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
+        g2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
+        call('fw_dwconv_fwd', dt(h1.dtype), g1, g1.stride(0), weight, bias, h2, g2, h2.stride(0), B, H, W, C)
+        ctx.save_for_backward(h1, g1, weight)
+        ctx.bias = bias
+        ctx.geo = (B, H, W)
+        ctx.mark_non_differentiable(g2)
+        return h2, g2
+
+    @staticmethod
+    def backward(ctx, dh2, _):
+        h1, g1, weight = ctx.saved_tensors
         B, H, W = ctx.geo
         C = h1.shape[1]
         dh2 = aligned(dh2)
-        dw, db = _zeros((C, 9), h1.device), _zeros((C,), h1.device)
+        dw, rw = _grad_target(weight, (C, 9))
+        db, rb = _grad_target(ctx.bias)
         dh1 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
-        call('fw_dwconv_bwd', dt(h1.dtype), dh2, dh2.stride(0), h1, h1.stride(0), weight, dh1, dh1.stride(0), dw, db, B, H, W, C)
-        return dh1, dw.view_as(weight), db, None, None, None
+        call('fw_dwconv_bwd', dt(h1.dtype), dh2, dh2.stride(0), g1, h1, h1.stride(0), weight, dh1, dh1.stride(0), dw, db, B, H, W, C)
+        return dh1, None, (rw.view_as(weight) if rw is not None else None), rb, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -281,6 +315,7 @@ class DownsampleFn(torch.autograd.Function):
         y = torch.empty((col.shape[0], Co), dtype=torch.float32, device=x.device)
         ops.gemm(col, shadow(weight, 'conv4'), col.shape[0], Co, 16 * C, out=y, bias=bias)
         ctx.save_for_backward(x, weight)
+        ctx.bias = bias
         ctx.geo = (B, H, W)
         return y
 
@@ -292,13 +327,16 @@ class DownsampleFn(torch.autograd.Function):
         Mo = dy.shape[0]
         g = ops.cast_rows(dy, config.compute_dtype) if config.compute_dtype != torch.float32 else aligned(dy)
         col = ops.im2col4(x, B, H, W, config.compute_dtype)
-        dwk = _wgrad(g, col, Co, 16 * C, Mo)
-        dw = _zeros((Co, C, 16), x.device)
+        dwk = _zeros((Co, 16 * C), x.device)
+        db, rb = _grad_target(ctx.bias)
+        ops.gemm(g, col, Co, 16 * C, Mo, x_trans=True, w_trans=True, out=dwk, accumulate=True,
+                 splitk=ops.pick_splitk(Co, 16 * C, Mo, g.dtype), xsum=db)
+        dw, rw = _grad_target(weight, (Co, C, 16))
         ops.permute3(dwk, dw, (Co, 16, C), (16 * C, 1, 16), accumulate=True)
         del col
         dcol = ops.gemm(g, shadow(weight, 'conv4'), Mo, 16 * C, Co, w_trans=True)
         dx = ops.col2im4(dcol, B, H, W, C)
-        return dx, dw.view_as(weight), _bgrad(dy, Co), None, None, None
+        return dx, (rw.view_as(weight) if rw is not None else None), rb, None, None, None
 
 
 class UpsampleCatFn(torch.autograd.Function):
@@ -314,6 +352,7 @@ class UpsampleCatFn(torch.autograd.Function):
         ops.pixel_shuffle(g, bias, out[:, :Cout], B, H, W, Cout)
         ops.copy_rows(skip, out[:, Cout:])
         ctx.save_for_backward(x, weight)
+        ctx.bias = bias
         ctx.geo = (B, H, W, Cs)
         return out
 
@@ -325,15 +364,17 @@ class UpsampleCatFn(torch.autograd.Function):
         M = x.shape[0]
         dg = ops.pixel_unshuffle(dcat[:, :Cout], B, H, W, Cout, config.compute_dtype)
         xq = ops.cast_rows(x, config.compute_dtype) if config.compute_dtype != torch.float32 else x
-        dwt = _wgrad(dg, xq, 4 * Cout, Cin, M)
-        dw = _zeros((Cin, Cout, 4), x.device)
+        dwt = _zeros((4 * Cout, Cin), x.device)
+        ops.gemm(dg, xq, 4 * Cout, Cin, M, x_trans=True, w_trans=True, out=dwt, accumulate=True,
+                 splitk=ops.pick_splitk(4 * Cout, Cin, M, dg.dtype))
+        dw, rw = _grad_target(weight, (Cin, Cout, 4))
         ops.permute3(dwt, dw, (4, Cout, Cin), (1, 4, Cout * 4), accumulate=True)
         dx = ops.gemm(dg, shadow(weight, 'convT2'), M, Cin, 4 * Cout, w_trans=True, out_dtype=torch.float32)
-        db = _zeros((Cout,), x.device)
+        db, rb = _grad_target(ctx.bias)
         ops.colsum(dcat[:, :Cout], db)
         dskip = torch.empty((dcat.shape[0], Cs), dtype=torch.float32, device=x.device)
         ops.copy_rows(dcat[:, Cout:], dskip)
-        return dx, dskip, dw.view_as(weight), db, None, None, None
+        return dx, dskip, (rw.view_as(weight) if rw is not None else None), rb, None, None, None
 
 
 class InputProjFn(torch.autograd.Function):

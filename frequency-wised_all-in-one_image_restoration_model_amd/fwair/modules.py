@@ -60,17 +60,17 @@ class LeFF(nn.Module):
     def run(self, xn, residual, rowscale, batch):
         rows = xn.shape[0]
         h = _tokens_hw(rows, batch)
-        h1 = Fn.linear(xn, self.linear1[0].weight, self.linear1[0].bias)
-        h2 = Fn.DwConvFn.apply(h1, self.conv[0].weight, self.conv[0].bias, batch, h, h)
-        return Fn.linear(h2, self.linear2[0].weight, self.linear2[0].bias, residual=residual, rowscale=rowscale,
-                         rows_per_scale=h * h, x_gelu=True)
+        h1, g1 = Fn.linear(xn, self.linear1[0].weight, self.linear1[0].bias, gelu_out=True)
+        h2, g2 = Fn.DwConvFn.apply(h1, g1, self.conv[0].weight, self.conv[0].bias, batch, h, h)
+        return Fn.linear(g2, self.linear2[0].weight, self.linear2[0].bias, residual=residual, rowscale=rowscale,
+                         rows_per_scale=h * h, x_pre=h2)
 
     def forward(self, x):                       # API parity: [B, HW, C] f32 -> [B, HW, C]
         B, HW, C = x.shape
         xn = Fn.CastFn.apply(x.reshape(B * HW, C))
-        y = Fn.linear(Fn.DwConvFn.apply(Fn.linear(xn, self.linear1[0].weight, self.linear1[0].bias), self.conv[0].weight,
-                                        self.conv[0].bias, B, int(math.isqrt(HW)), int(math.isqrt(HW))),
-                      self.linear2[0].weight, self.linear2[0].bias, x_gelu=True, out_f32=True)
+        h1, g1 = Fn.linear(xn, self.linear1[0].weight, self.linear1[0].bias, gelu_out=True)
+        h2, g2 = Fn.DwConvFn.apply(h1, g1, self.conv[0].weight, self.conv[0].bias, B, int(math.isqrt(HW)), int(math.isqrt(HW)))
+        y = Fn.linear(g2, self.linear2[0].weight, self.linear2[0].bias, x_pre=h2, out_f32=True)
         return y.view(B, HW, C)
 
 

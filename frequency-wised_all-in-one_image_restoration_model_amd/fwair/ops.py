@@ -19,7 +19,7 @@ def empty(rows, cols, dtype, device):
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(x, w, M, N, K, *, x_trans=False, w_trans=False, x_op=0, w_op=0, out=None, out_dtype=None, bias=None,
          act=0, slope=0.0, aux=None, rowscale=None, rows_per_scale=1, residual=None, accumulate=False, splitk=1,
-         alpha=1.0):
+         alpha=1.0, out_gelu=None, xsum=None):
     """C[M,N] = epi(alpha * X W^T).  x: [M,K] (or [K,M] when x_trans), w: [N,K] (or [K,N] when w_trans)."""
     assert x.dtype == w.dtype
     if out is None:
@@ -27,7 +27,8 @@ def gemm(x, w, M, N, K, *, x_trans=False, w_trans=False, x_op=0, w_op=0, out=Non
     out_f32 = int(out.dtype == torch.float32)
     call('fw_gemm', dt(x.dtype), x, _ld(x), int(x_trans), x_op, w, _ld(w), int(w_trans), w_op, out, _ld(out), out_f32,
          int(accumulate), M, N, K, float(alpha), bias, act, float(slope), aux, _ld(aux) if aux is not None else 0,
-         rowscale, rows_per_scale, residual, _ld(residual) if residual is not None else 0, splitk)
+         rowscale, rows_per_scale, residual, _ld(residual) if residual is not None else 0, splitk,
+         out_gelu, _ld(out_gelu) if out_gelu is not None else 0, xsum)
     return out
 
 
@@ -102,15 +103,16 @@ def rel_index(device):
 
 
 # ------------------------------------------------------------------------------------------------ LeFF dwconv
-def dwconv_fwd(h1, w, bias, B, H, W):
-    h2 = torch.empty_like(h1)
-    call('fw_dwconv_fwd', dt(h1.dtype), h1, _ld(h1), w, bias, h2, _ld(h2), B, H, W, h1.shape[1])
-    return h2
+def dwconv_fwd(g1, w, bias, B, H, W):
+    """-> (h2, g2 = GELU(h2))"""
+    h2, g2 = torch.empty_like(g1), torch.empty_like(g1)
+    call('fw_dwconv_fwd', dt(g1.dtype), g1, _ld(g1), w, bias, h2, g2, _ld(h2), B, H, W, g1.shape[1])
+    return h2, g2
 
 
-def dwconv_bwd(dh2, h1, w, dw, dbias, B, H, W):
+def dwconv_bwd(dh2, g1, h1, w, dw, dbias, B, H, W):
     dh1 = torch.empty_like(h1)
-    call('fw_dwconv_bwd', dt(h1.dtype), dh2, _ld(dh2), h1, _ld(h1), w, dh1, _ld(dh1), dw, dbias, B, H, W, h1.shape[1])
+    call('fw_dwconv_bwd', dt(h1.dtype), dh2, _ld(dh2), g1, h1, _ld(h1), w, dh1, _ld(dh1), dw, dbias, B, H, W, h1.shape[1])
     return dh1
 
 

@@ -28,11 +28,13 @@ extern "C" {
  * x_op / w_op = 1: GELU applied to the operand while it is staged (leff.py:100,106 activations).
  * act: 0 none, 1 LeakyReLU(slope), 2 multiply by GELU'(aux[m][n]), 3 GELU.
  * epilogue order: alpha, +bias[n], act, *rowscale[m / rows_per_scale] (DropPath), +residual[m][n] (f32).
- * out_f32: C is f32 (else T).  accumulate: atomicAdd into f32 C (required when splitk > 1). */
+ * out_f32: C is f32 (else T).  accumulate: atomicAdd into f32 C (required when splitk > 1).
+ * C2 (optional, T): second output GELU(v) (LeFF keeps pre- and post-activation).  xsum (optional, x_trans only):
+ * xsum[m] += sum_k X(m,k), i.e. the bias gradient falls out of the weight-gradient GEMM. */
 int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op, const void* W, long ldw, int w_trans, int w_op,
             void* C, long ldc, int out_f32, int accumulate, int M, int N, int K, float alpha, const float* bias, int act,
             float slope, const void* aux, long ldaux, const float* rowscale, int rows_per_scale, const float* residual,
-            long ldr, int splitk, void* stream);
+            long ldr, int splitk, void* C2, long ldc2, float* xsum, void* stream);
 
 /* ---- LayerNorm over the f32 stream -> T (decoder_Uformer.py:567,594,666,744; encoder_Uformer.py:941) -- */
 int fw_layernorm_fwd(int dtype, const float* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
@@ -61,11 +63,12 @@ int fw_attn_bwd(int dtype, int D, int nkt, int lfs, const void* q, const void* k
                 const void* lfs_tab, void* dq, void* dk, void* dv, void* dk2, void* dv2, long ldd, float* dbias,
                 float* dcoef, int B, int H, int W, int heads, int L, int mode, int shift, float scale, void* stream);
 
-/* ---- LeFF depthwise 3x3 (net/utils/leff.py:104-111): h2 = dwconv(GELU(h1)) + bias; w f32 [C][9] ------ */
-int fw_dwconv_fwd(int dtype, const void* h1, long ld1, const float* w, const float* bias, void* h2, long ld2, int B, int H,
-                  int W, int C, void* stream);
-int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* h1, long ld1, const float* w, void* dh1, long ldo,
-                  float* dw, float* dbias, int B, int H, int W, int C, void* stream);
+/* ---- LeFF depthwise 3x3 (net/utils/leff.py:104-111).  Both pre-activations (h) and GELU outputs (g) are kept:
+ * fwd: h2 = dwconv(g1) + bias, g2 = GELU(h2);  bwd: dh1 = GELU'(h1) * convT(dh2), dw/dbias accumulated.  w: f32 [C][9]. */
+int fw_dwconv_fwd(int dtype, const void* g1, long ld1, const float* w, const float* bias, void* h2, void* g2, long ld2, int B,
+                  int H, int W, int C, void* stream);
+int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g1, const void* h1, long ld1, const float* w, void* dh1,
+                  long ldo, float* dw, float* dbias, int B, int H, int W, int C, void* stream);
 
 /* ---- Downsample conv k4 s2 p1 (decoder_Uformer.py:414-430) as GEMM: K order (ky, kx, ci) -------------- */
 int fw_im2col4(int dtype, const float* x, long ldx, void* col, int B, int H, int W, int C, void* stream);

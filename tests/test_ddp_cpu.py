@@ -38,7 +38,7 @@ def _worker(rank, world, port, wire, out):
         assert params[0].grad.data_ptr() == g.data_ptr()                # autograd accumulated in place
         red()
     if rank == 0:
-        torch.save(g.clone(), out)
+        torch.save(torch.cat([p.grad.reshape(-1) for p in params]), out)      # per-parameter views (the flat buffer is padded)
     dist.destroy_process_group()
 
 
@@ -53,7 +53,7 @@ def _run(wire, tmp_path, port):
     loss = sum(torch.nn.functional.l1_loss(net(x[r * 4:(r + 1) * 4]), y[r * 4:(r + 1) * 4]) for r in range(2)) / 2
     loss.backward()
     ref = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
-    return got[:ref.numel()], ref
+    return got, ref
 
 
 def test_allreduce_fp32(tmp_path):

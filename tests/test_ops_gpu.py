@@ -71,6 +71,9 @@ def test_gemm_nt_epilogues(dtype, M, N, K):
     a64 = aux.double()
     gp = 0.5 * (1 + torch.erf(a64 / math.sqrt(2))) + a64 * torch.exp(-0.5 * a64 * a64) / math.sqrt(2 * math.pi)
     close(y, F.linear(x, w).double() * gp, TOL[dtype], 'gelu-grad epilogue')
+    g = torch.empty(M, N, device=DEV, dtype=dtype)
+    y = ops().gemm(xd, wd, M, N, K, bias=bias.to(DEV), out_gelu=g)
+    close(g, F.gelu(F.linear(x, w, bias)), TOL[dtype], 'second output GELU(v)')
     y = ops().gemm(xd, wd, M, N, K, x_op=1, out_dtype=torch.float32)
     close(y, F.linear(q(F.gelu(x), dtype) if dtype == torch.bfloat16 else F.gelu(x), w), TOL[dtype] * 2, 'gelu on load')
 
@@ -115,8 +118,10 @@ def test_gemm_tn_dw(dtype, M, N, K, split):
     dy, x = q(rnd(K, M), dtype), q(rnd(K, N, seed=1), dtype)
     out = torch.zeros(M, N, device=DEV)
     pad = lambda t: torch.cat([t, torch.full((t.shape[0], (-t.shape[1]) % 8), float('nan'))], 1).to(DEV, dtype)[:, :t.shape[1]]
-    ops().gemm(pad(dy), pad(x), M, N, K, x_trans=True, w_trans=True, out=out, accumulate=True, splitk=split)
+    xsum = torch.zeros(M, device=DEV)
+    ops().gemm(pad(dy), pad(x), M, N, K, x_trans=True, w_trans=True, out=out, accumulate=True, splitk=split, xsum=xsum)
     close(out, dy.t() @ x, TOL[dtype], 'TN')
+    close(xsum, dy.sum(0), 1e-4, 'fused column sums (bias gradient)')
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
@@ -237,13 +242,15 @@ def test_dwconv(dtype):
     h1 = q(rnd(B * H * W, C), dtype).requires_grad_(True)
     w = (rnd(C, 1, 3, 3, seed=1) * 0.3).requires_grad_(True)
     b = (rnd(C, seed=2) * 0.1).requires_grad_(True)
+    g1 = q(F.gelu(h1.detach()), dtype)                       # the stored post-activation twin (rounded like the kernel stores it)
     ref = F.conv2d(F.gelu(h1).view(B, H, W, C).permute(0, 3, 1, 2), w, b, padding=1, groups=C).permute(0, 2, 3, 1).reshape(B * H * W, C)
-    h2 = ops().dwconv_fwd(h1.detach().to(DEV, dtype), w.detach().view(C, 9).to(DEV), b.detach().to(DEV), B, H, W)
+    h2, g2 = ops().dwconv_fwd(g1.to(DEV, dtype), w.detach().view(C, 9).to(DEV), b.detach().to(DEV), B, H, W)
     close(h2, ref, TOL[dtype], 'h2')
+    close(g2, F.gelu(ref), TOL[dtype], 'g2')
     dh2 = q(rnd(B * H * W, C, seed=3), dtype)
     ref.backward(dh2)
     dw, db = torch.zeros(C, 9, device=DEV), torch.zeros(C, device=DEV)
-    dh1 = ops().dwconv_bwd(dh2.to(DEV, dtype), h1.detach().to(DEV, dtype), w.detach().view(C, 9).to(DEV), dw, db, B, H, W)
+    dh1 = ops().dwconv_bwd(dh2.to(DEV, dtype), g1.to(DEV, dtype), h1.detach().to(DEV, dtype), w.detach().view(C, 9).to(DEV), dw, db, B, H, W)
     close(dh1, h1.grad, TOL[dtype] * 2, 'dh1')
     close(dw, w.grad.view(C, 9), TOL[dtype] * 2, 'dw')
     close(db, b.grad, TOL[dtype] * 2, 'db')

@@ -118,32 +118,39 @@ __global__ void dwconv_fwd_kernel(const T* __restrict__ g1, long ld1, const floa
     }
 }
 
-// thread = (token stripe, channel vector); STRIPE consecutive tokens per thread, partial weight sums in registers.
+// block = 32 token stripes x 8 channel vectors; a thread walks STRIPE consecutive tokens of one vector with its
+// weight-gradient partials in registers; partials are reduced over the block's 32 stripes (shuffles + LDS) before ONE
+// atomic per (channel, tap) and block -- every block of a layer hits the same few hundred words otherwise.
 template <typename T, int STRIPE>
-__global__ void dwconv_bwd_kernel(const T* __restrict__ dh2, long ldg, const T* __restrict__ g1, const T* __restrict__ h1, long ld1,
-                                  const float* __restrict__ w, T* __restrict__ dh1, long ldo, float* __restrict__ dw, float* __restrict__ dbias,
-                                  int B, int H, int W, int C) {
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ dh2, long ldg, const T* __restrict__ g1, const T* __restrict__ h1,
+                                                         long ld1, const float* __restrict__ w, T* __restrict__ dh1, long ldo,
+                                                         float* __restrict__ dw, float* __restrict__ dbias, int B, int H, int W, int C) {
     constexpr int E = TT<T>::E16;
+    __shared__ float red[8 * E * 10];
     const int nv = C / E;
+    const int nvg = (nv + 7) / 8;
     const long ntok = (long)B * H * W;
-    const long nstripes = (ntok + STRIPE - 1) / STRIPE;
-    for (long i = gtid(); i < nstripes * nv; i += gstride()) {
-        const int v = (int)(i % nv); const long st = i / nv;
-        const int c0 = v * E;
-        float wr[E][9], gw[E][9], gb[E];
+    const int vl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int v = (blockIdx.x % nvg) * 8 + vl;
+    const long st = (long)(blockIdx.x / nvg) * 32 + sl;
+    const bool live = v < nv;
+    const int c0 = (live ? v : 0) * E;
+    for (int i = threadIdx.x; i < 8 * E * 10; i += 256) red[i] = 0.f;
+    float wr[E][9], gw[E][10];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            gb[e] = 0.f;
+    for (int e = 0; e < E; ++e) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) { wr[e][t] = w[(c0 + e) * 9 + t]; gw[e][t] = 0.f; }
-        }
+        for (int t = 0; t < 9; ++t) { wr[e][t] = w[(c0 + e) * 9 + t]; gw[e][t] = 0.f; }
+        gw[e][9] = 0.f;
+    }
+    if (live)
         for (long tok = st * STRIPE; tok < ntok && tok < (st + 1) * STRIPE; ++tok) {
             const int x = (int)(tok % W); const int y = (int)((tok / W) % H); const long b = tok / ((long)W * H);
             float g0[E], hc[E], din[E];
             ldvec<T>(dh2 + tok * ldg + c0, g0);
             ldvec<T>(h1 + tok * ld1 + c0, hc);
 #pragma unroll
-            for (int e = 0; e < E; ++e) { gb[e] += g0[e]; din[e] = 0.f; }
+            for (int e = 0; e < E; ++e) { gw[e][9] += g0[e]; din[e] = 0.f; }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -167,11 +174,23 @@ __global__ void dwconv_bwd_kernel(const T* __restrict__ dh2, long ldg, const T* 
             for (int e = 0; e < E; ++e) din[e] *= gelu_grad_f(hc[e]);
             stvec<T>(dh1 + tok * ldo + c0, din);
         }
+    __syncthreads();
+    // reduce over the 8 stripes of this wave (lanes with equal vl), then over the 4 waves through LDS
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            atomicAdd(dbias + c0 + e, gb[e]);
+    for (int e = 0; e < E; ++e)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) atomicAdd(dw + (c0 + e) * 9 + t, gw[e][t]);
+        for (int t = 0; t < 10; ++t) {
+            float s = gw[e][t];
+            s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            if ((threadIdx.x & 63) < 8) atomicAdd(&red[(vl * E + e) * 10 + t], s);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * E * 10; i += 256) {
+        const int t = i % 10, ce = i / 10;
+        const int c = (blockIdx.x % nvg) * 8 * E + ce;
+        if (c < C) {
+            if (t < 9) atomicAdd(dw + c * 9 + t, red[i]);
+            else atomicAdd(dbias + c, red[i]);
         }
     }
 }
@@ -301,8 +320,11 @@ __global__ void inproj_fwd_kernel(const float* __restrict__ img, const float* __
 }
 // dw[c][ci][ky][kx] += sum_t dy'[t][c] img[..];  db[c] += sum_t dy'[t][c];   dy' = dy * lrelu'(out)
 template <int STRIPE>
-__global__ void inproj_bwd_kernel(const float* __restrict__ img, const float* __restrict__ out, long ldo, const float* __restrict__ dy, long ldy,
-                                  float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int C, float slope) {
+__global__ __launch_bounds__(256) void inproj_bwd_kernel(const float* __restrict__ img, const float* __restrict__ out, long ldo, const float* __restrict__ dy, long ldy,
+                                                         float* __restrict__ dw, float* __restrict__ db, int B, int H, int W, int C, float slope) {
+    extern __shared__ float red[];                       // [C][28]: block partials before ONE atomic per word
+    for (int i = threadIdx.x; i < C * 28; i += 256) red[i] = 0.f;
+    __syncthreads();
     const long ntok = (long)B * H * W;
     const long nstripes = (ntok + STRIPE - 1) / STRIPE;
     for (long i = gtid(); i < nstripes * C; i += gstride()) {
@@ -325,8 +347,13 @@ __global__ void inproj_bwd_kernel(const float* __restrict__ img, const float* __
                     }
                 }
         }
-        atomicAdd(db + c, gb);
-        for (int t = 0; t < 27; ++t) atomicAdd(dw + c * 27 + t, g[t]);
+        atomicAdd(&red[c * 28 + 27], gb);
+        for (int t = 0; t < 27; ++t) atomicAdd(&red[c * 28 + t], g[t]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 28; i += 256) {
+        const int c = i / 28, t = i % 28;
+        if (t < 27) atomicAdd(dw + c * 27 + t, red[i]); else atomicAdd(db + c, red[i]);
     }
 }
 
@@ -388,8 +415,11 @@ __global__ void outproj_bwd_data_kernel(const float* __restrict__ dout, const fl
     }
 }
 template <int STRIPE>
-__global__ void outproj_bwd_w_kernel(const float* __restrict__ dout, const float* __restrict__ fea, long ldf, float* __restrict__ dw,
-                                     float* __restrict__ db, int B, int H, int W, int C) {
+__global__ __launch_bounds__(256) void outproj_bwd_w_kernel(const float* __restrict__ dout, const float* __restrict__ fea, long ldf, float* __restrict__ dw,
+                                                            float* __restrict__ db, int B, int H, int W, int C) {
+    extern __shared__ float red[];                       // [C][27] + [3]
+    for (int i = threadIdx.x; i < C * 27 + 3; i += 256) red[i] = 0.f;
+    __syncthreads();
     const long ntok = (long)B * H * W;
     const long nstripes = (ntok + STRIPE - 1) / STRIPE;
     for (long i = gtid(); i < nstripes * C; i += gstride()) {
@@ -411,9 +441,14 @@ __global__ void outproj_bwd_w_kernel(const float* __restrict__ dout, const float
                 }
             }
         }
-        if (c == 0) for (int co = 0; co < 3; ++co) atomicAdd(db + co, gb[co]);
-        for (int co = 0; co < 3; ++co)
-            for (int t = 0; t < 9; ++t) atomicAdd(dw + (co * C + c) * 9 + t, g[co * 9 + t]);
+        if (c == 0) for (int co = 0; co < 3; ++co) atomicAdd(&red[C * 27 + co], gb[co]);
+        for (int t = 0; t < 27; ++t) atomicAdd(&red[c * 27 + t], g[t]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 27 + 3; i += 256) {
+        if (i >= C * 27) { atomicAdd(db + (i - C * 27), red[i]); continue; }
+        const int c = i / 27, t = i % 27;                 // t = co*9 + tap
+        atomicAdd(dw + ((t / 9) * C + c) * 9 + t % 9, red[i]);
     }
 }
 
@@ -486,6 +521,25 @@ template <typename T>
 __global__ void lrelu_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long n, float slope) {
     for (long i = gtid(); i < n; i += gstride()) dx[i] = TT<T>::ld(dy + i) * (x[i] > 0.f ? 1.f : slope);
 }
+// dst[i] (+)= sum_z slab[z*zstride + i]: the reduction step of a split-K GEMM (replaces thousands of same-address atomics)
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long n, long zstride, float* __restrict__ dst, int accumulate, int zper) {
+    const long i4 = gtid();
+    if (i4 * 4 >= n) return;
+    const int z0 = blockIdx.y * zper, z1 = min(nz, z0 + zper);
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i4 * 4 + 3 < n) {
+        for (int z = z0; z < z1; ++z) s += *reinterpret_cast<const f32x4*>(slab + (long)z * zstride + i4 * 4);
+    } else {
+        for (int z = z0; z < z1; ++z)
+            for (int e = 0; e < 4; ++e) if (i4 * 4 + e < n) s[e] += slab[(long)z * zstride + i4 * 4 + e];
+    }
+    for (int e = 0; e < 4; ++e) {
+        if (i4 * 4 + e >= n) break;
+        if (gridDim.y > 1) atomicAdd(dst + i4 * 4 + e, s[e]);        // <= nz/zper adders per address
+        else if (accumulate) dst[i4 * 4 + e] += s[e];
+        else dst[i4 * 4 + e] = s[e];
+    }
+}
 __global__ void fill_kernel(float* __restrict__ p, long n, float v) {
     for (long i = gtid(); i < n; i += gstride()) p[i] = v;
 }
@@ -543,12 +597,16 @@ extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g
     const int e = dtype == FW_DT_BF16 ? 8 : 4;
     FW_CHECK_ARG(dh2 && g1 && h1 && w && dh1 && dw && dbias && C % e == 0 && ld1 % e == 0 && ldg % e == 0 && ldo % e == 0);
     constexpr int STRIPE = 32;
-    const long n = (((long)B * H * W + STRIPE - 1) / STRIPE) * (C / e);
+    const int nvg = (C / e + 7) / 8;
+    const long nsg = (((long)B * H * W + STRIPE - 1) / STRIPE + 31) / 32;
+    const dim3 grid((unsigned)(nsg * nvg));
     if (dtype == FW_DT_BF16)
-        LAUNCH((dwconv_bwd_kernel<bf16raw, STRIPE>), n, (const bf16raw*)dh2, ldg, (const bf16raw*)g1, (const bf16raw*)h1, ld1, w, (bf16raw*)dh1,
-               ldo, dw, dbias, B, H, W, C);
-    LAUNCH((dwconv_bwd_kernel<float, STRIPE>), n, (const float*)dh2, ldg, (const float*)g1, (const float*)h1, ld1, w, (float*)dh1, ldo, dw, dbias,
-           B, H, W, C);
+        hipLaunchKernelGGL((dwconv_bwd_kernel<bf16raw, STRIPE>), grid, dim3(256), 0, ST, (const bf16raw*)dh2, ldg, (const bf16raw*)g1,
+                           (const bf16raw*)h1, ld1, w, (bf16raw*)dh1, ldo, dw, dbias, B, H, W, C);
+    else
+        hipLaunchKernelGGL((dwconv_bwd_kernel<float, STRIPE>), grid, dim3(256), 0, ST, (const float*)dh2, ldg, (const float*)g1,
+                           (const float*)h1, ld1, w, (float*)dh1, ldo, dw, dbias, B, H, W, C);
+    FW_LAUNCH_RET();
 }
 extern "C" int fw_im2col4(int dtype, const float* x, long ldx, void* col, int B, int H, int W, int C, void* stream) {
     FW_CHECK_ARG(x && col && C % 4 == 0 && ldx % 4 == 0 && H % 2 == 0 && W % 2 == 0);
@@ -594,8 +652,10 @@ extern "C" int fw_inproj_fwd(const float* img, const float* w, const float* bias
 extern "C" int fw_inproj_bwd(const float* img, const float* out, long ldo, const float* dy, long ldy, float* dw, float* db, int B,
                              int H, int W, int C, float slope, void* stream) {
     FW_CHECK_ARG(img && out && dy && dw && db);
-    constexpr int STRIPE = 128;
-    LAUNCH((inproj_bwd_kernel<STRIPE>), (((long)B * H * W + STRIPE - 1) / STRIPE) * C, img, out, ldo, dy, ldy, dw, db, B, H, W, C, slope);
+    constexpr int STRIPE = 32;
+    hipLaunchKernelGGL((inproj_bwd_kernel<STRIPE>), dim3(grid_for((((long)B * H * W + STRIPE - 1) / STRIPE) * C, 1024)), dim3(TPB), (size_t)C * 28 * 4, ST,
+                       img, out, ldo, dy, ldy, dw, db, B, H, W, C, slope);
+    FW_LAUNCH_RET();
 }
 extern "C" int fw_outproj_fwd(const float* fea, long ldf, const float* w, const float* bias, const float* img, float* out, int B,
                               int H, int W, int C, void* stream) {
@@ -606,8 +666,10 @@ extern "C" int fw_outproj_bwd(const float* dout, const float* fea, long ldf, con
                               float* db, int B, int H, int W, int C, void* stream) {
     FW_CHECK_ARG(dout && fea && w && dfea && dw && db && C % 4 == 0 && ldf % 4 == 0 && lddf % 4 == 0);
     hipLaunchKernelGGL(outproj_bwd_data_kernel, dim3(grid_for((long)B * H * W * (C / 4))), dim3(TPB), 0, ST, dout, w, dfea, lddf, B, H, W, C);
-    constexpr int STRIPE = 128;
-    LAUNCH((outproj_bwd_w_kernel<STRIPE>), (((long)B * H * W + STRIPE - 1) / STRIPE) * C, dout, fea, ldf, dw, db, B, H, W, C);
+    constexpr int STRIPE = 32;
+    hipLaunchKernelGGL((outproj_bwd_w_kernel<STRIPE>), dim3(grid_for((((long)B * H * W + STRIPE - 1) / STRIPE) * C, 1024)), dim3(TPB),
+                       (size_t)(C * 27 + 3) * 4, ST, dout, fea, ldf, dw, db, B, H, W, C);
+    FW_LAUNCH_RET();
 }
 extern "C" int fw_l1_loss(const float* a, const float* b, float* da, long n, float gscale, float* loss, void* stream) {
     FW_CHECK_ARG(a && b && loss && n > 0);
@@ -645,6 +707,15 @@ extern "C" int fw_lrelu_bwd(int dtype, const void* dy, const float* x, float* dx
     FW_CHECK_ARG(dy && x && dx && n > 0);
     if (dtype == FW_DT_BF16) LAUNCH((lrelu_bwd_kernel<bf16raw>), n, (const bf16raw*)dy, x, dx, n, slope);
     LAUNCH((lrelu_bwd_kernel<float>), n, (const float*)dy, x, dx, n, slope);
+}
+// dst must be pre-initialised when accumulate != 0 or when nz > 64 (the z range is then split over blockIdx.y with atomics).
+extern "C" int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, void* stream) {
+    FW_CHECK_ARG(slab && dst && nz > 0 && n > 0 && zstride % 4 == 0 && ((uintptr_t)slab & 15) == 0);
+    FW_CHECK_ARG(accumulate || nz <= 64);
+    const int zper = 64;
+    dim3 grid((unsigned)((n / 4 + 1 + TPB - 1) / TPB), (unsigned)((nz + zper - 1) / zper));
+    hipLaunchKernelGGL(slab_reduce_kernel, grid, dim3(TPB), 0, ST, slab, nz, n, zstride, dst, accumulate, zper);
+    FW_LAUNCH_RET();
 }
 extern "C" int fw_fill(float* p, long n, float v, void* stream) {
     FW_CHECK_ARG(p && n > 0);

@@ -34,6 +34,7 @@ struct GemmArgs {
     int splitk; int kper;               // K range per z-slice (multiple of the K step)
     char* C2; long ldc2;                // optional second output GELU(v), type T
     float* xsum;                        // optional: xsum[m] += sum_k X(m,k) (x_trans only; the bias gradient of a dW GEMM)
+    long c_zstride, xsum_zstride;       // > 0: split-K slice z writes its partial tile / sums to C + z*stride (plain stores, no atomics)
     float alpha;
 };
 
@@ -233,13 +234,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     }
 
     if constexpr (XT) {
-        if (do_xsum) {
+        if (a.xsum != nullptr && blockIdx.y == 0) {          // block-uniform: reduce the 16 k-slices on chip, one atomic per row
             constexpr int E = TT<T>::E16, IB = BM / E;
+            float* red = reinterpret_cast<float*>(smem);       // the staging tiles are dead after the last barrier
+            if (threadIdx.x < BM) red[threadIdx.x] = 0.f;
+            __syncthreads();
             if ((int)threadIdx.x < IB * ((128 / TT<T>::SZ) / 4)) {
                 const int ib = threadIdx.x % IB;
 #pragma unroll
-                for (int e = 0; e < E; ++e)
-                    if (m_blk + ib * E + e < a.M) atomicAdd(a.xsum + m_blk + ib * E + e, xsum[e]);
+                for (int e = 0; e < E; ++e) atomicAdd(&red[ib * E + e], xsum[e]);
+            }
+            __syncthreads();
+            if (threadIdx.x < BM && m_blk + (int)threadIdx.x < a.M) {
+                if (a.xsum_zstride > 0) a.xsum[(long)blockIdx.z * a.xsum_zstride + m_blk + threadIdx.x] = red[threadIdx.x];
+                else atomicAdd(a.xsum + m_blk + threadIdx.x, red[threadIdx.x]);
             }
         }
     }
@@ -289,8 +297,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
                 else *reinterpret_cast<uint2*>(c2) = make_uint2(pack_bf2(g0, g1), pack_bf2(g2, g3));
             }
             if (a.out_f32) {
-                float* cp = reinterpret_cast<float*>(a.C) + (long)m * a.ldc + n0;
-                if (a.accumulate) {
+                float* cp = reinterpret_cast<float*>(a.C) + (long)blockIdx.z * a.c_zstride + (long)m * a.ldc + n0;
+                if (a.accumulate && a.c_zstride == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
                 } else {
@@ -337,7 +345,8 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
                        int w_trans, int w_op, void* C, long ldc, int out_f32, int accumulate, int M, int N,
                        int K, float alpha, const float* bias, int act, float slope, const void* aux,
                        long ldaux, const float* rowscale, int rows_per_scale, const float* residual,
-                       long ldr, int splitk, void* C2, long ldc2, float* xsum, void* stream) {
+                       long ldr, int splitk, void* C2, long ldc2, float* xsum, long c_zstride, long xsum_zstride,
+                       void* stream) {
     const int sz = dtype == FW_DT_BF16 ? 2 : 4;
     const int e16 = 16 / sz;
     FW_CHECK_ARG(dtype == FW_DT_F32 || dtype == FW_DT_BF16);
@@ -349,7 +358,8 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
     if (!x_trans) FW_CHECK_ARG((K * sz) % 4 == 0 && ldx >= K); else FW_CHECK_ARG(ldx >= M);
     if (!w_trans) FW_CHECK_ARG((K * sz) % 4 == 0 && ldw >= K); else FW_CHECK_ARG(ldw >= N);
     FW_CHECK_ARG(!accumulate || out_f32 || dtype == FW_DT_F32);
-    FW_CHECK_ARG(splitk >= 1 && (splitk == 1 || accumulate));
+    FW_CHECK_ARG(splitk >= 1 && (splitk == 1 || accumulate || c_zstride > 0));
+    FW_CHECK_ARG(c_zstride == 0 || (out_f32 && c_zstride % 4 == 0));
     FW_CHECK_ARG(act >= 0 && act <= 3 && (act != 2 || aux));
     FW_CHECK_ARG(!rowscale || rows_per_scale > 0);
     if (bias) FW_CHECK_ARG(((uintptr_t)bias & 15) == 0);
@@ -364,13 +374,14 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
     a.out_f32 = (out_f32 || dtype == FW_DT_F32) ? 1 : 0;
     a.accumulate = accumulate;
     a.splitk = splitk;
-    a.C2 = (char*)C2; a.ldc2 = ldc2; a.xsum = xsum;
+    a.C2 = (char*)C2; a.ldc2 = ldc2; a.xsum = xsum; a.c_zstride = c_zstride; a.xsum_zstride = xsum_zstride;
     FW_CHECK_ARG(!xsum || x_trans);
     FW_CHECK_ARG(!C2 || (((uintptr_t)C2 & (4 * sz - 1)) == 0 && ldc2 % 4 == 0));
     a.kper = fw_cdiv(fw_cdiv(K, kt), splitk) * kt;
     a.alpha = alpha;
     hipStream_t st = (hipStream_t)stream;
-    const bool small_n = N <= 64;
+    // 128x64 tiles when N is narrow or when 128x128 tiles would leave most of the 256 CUs (2 blocks each) idle
+    const bool small_n = N <= 64 || (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk < 384;
     if (dtype == FW_DT_BF16) {
         return small_n ? dispatch_trans<bf16raw, 64>(a, x_trans, w_trans, st)
                        : dispatch_trans<bf16raw, 128>(a, x_trans, w_trans, st);

@@ -56,11 +56,12 @@ def train_loss(restored, clean, logits, w, gscale=1.0):
 # flat storage
 # ---------------------------------------------------------------------------------------------------------------
 def _layout(params):
-    """Element offset of every parameter in a flat buffer; each starts 16-byte aligned (vector loads of biases, GEMM operands)."""
+    """Element offset of every parameter in a flat buffer; each starts on a multiple of 8 elements, i.e. 16-byte aligned
+    both in the f32 buffer and in its bf16 shadow (vector loads of biases, GEMM operands)."""
     offs, o = [], 0
     for p in params:
         offs.append(o)
-        o += (p.numel() + 3) // 4 * 4
+        o += (p.numel() + 7) // 8 * 8
     return offs, o
 
 
@@ -141,6 +142,18 @@ class TrainEngine:
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
         self.hyper = torch.tensor([lr, 1.0, 1.0, 0.0], dtype=torch.float32, device=dev)
+        # bf16 operand shadows of every 2-D weight whose rows stay 16-byte aligned: written by the Adam / EMA kernels
+        self.shadow_p = self.shadow_k = None
+        if Fn.config.compute_dtype == torch.bfloat16:
+            self.shadow_p = torch.empty(self.n, dtype=torch.bfloat16, device=dev)
+            self.shadow_k = torch.empty(self.n_enc, dtype=torch.bfloat16, device=dev)
+            call('fw_cast_flat', 1, self.flat_p, self.shadow_p, self.n)
+            call('fw_cast_flat', 1, self.flat_k, self.shadow_k, self.n_enc)
+            for plist, sh in ((self.trainable, self.shadow_p), (enc_k, self.shadow_k)):
+                offs, _ = _layout(plist)
+                for p, o in zip(plist, offs):
+                    if p.dim() == 2 and (p.shape[1] * 2) % 16 == 0:
+                        p._fw_shadow = sh[o:o + p.numel()].view_as(p)
         moco._ema_hook = self._ema
         self.allreduce = GradAllReducer(self.flat_g, wire_dtype=grad_wire_dtype)
         if dist.is_initialized() and dist.get_world_size() > 1:
@@ -156,7 +169,7 @@ class TrainEngine:
         self.hyper[0:1].fill_(float(lr))
 
     def _ema(self):
-        call('fw_ema', 0, self.flat_k, self.flat_p, None, self.n_enc, self.net.E.E.m)
+        call('fw_ema', 1 if self.shadow_k is not None else 0, self.flat_k, self.flat_p, self.shadow_k, self.n_enc, self.net.E.E.m)
         Fn.config.shadow_epoch += 1
 
     def _fwd_bwd(self, xq, xk, clean):
@@ -168,7 +181,8 @@ class TrainEngine:
 
     def _optim(self):
         call('fw_adam_tick', self.hyper, self.betas[0], self.betas[1])
-        call('fw_adam', 0, self.flat_p, self.flat_g, self.m, self.v, None, self.n, self.hyper, self.betas[0], self.betas[1], self.eps)
+        call('fw_adam', 1 if self.shadow_p is not None else 0, self.flat_p, self.flat_g, self.m, self.v, self.shadow_p, self.n, self.hyper,
+             self.betas[0], self.betas[1], self.eps)
         Fn.config.shadow_epoch += 1
 
     def step_eager(self, xq, xk, clean):

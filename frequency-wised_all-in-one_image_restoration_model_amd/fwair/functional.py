@@ -47,6 +47,9 @@ def shadow(param, kind='plain'):
           'convT2' [Cin, Cout, 2, 2] -> [4*Cout, Cin] (row order i, j, co)."""
     dtype = config.compute_dtype
     p = param.detach()
+    fs = getattr(param, '_fw_shadow', None)
+    if fs is not None and kind == 'plain' and fs.dtype == dtype:
+        return fs                                   # engine-managed: view of the flat shadow the Adam / EMA kernels write
     if kind == 'plain' and dtype == torch.float32:
         w = p.reshape(p.shape[0], -1)
         if (w.stride(0) * 4) % 16 == 0:
@@ -98,8 +101,7 @@ def _wgrad(g, x, n, k, m, weight, bias=None):
     same pass (xsum).  Returns the autograd values (dW, db)."""
     dw, rw = _grad_target(weight, (n, k))
     db, rb = _grad_target(bias) if bias is not None else (None, None)
-    ops.gemm(g, x, n, k, m, x_trans=True, w_trans=True, out=dw, accumulate=True,
-             splitk=ops.pick_splitk(n, k, m, g.dtype), xsum=db)
+    ops.wgrad(g, x, n, k, m, dw, db)
     return (rw.view_as(weight) if rw is not None else None), rb
 
 
@@ -186,6 +188,32 @@ class LinearFn(torch.autograd.Function):
             else:
                 dx = d
         return dx, dw, db, (dy if has_res else None), None, None, dpre, None, None
+
+
+class LnResFn(torch.autograd.Function):
+    """(x) -> (x, LayerNorm(x)): the stream feeds both the branch and the residual add; returning it as a second output
+    lets backward fuse  dx = d_residual + LN'(d_branch)  into the LayerNorm kernel instead of a separate add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        rows, C = x.shape
+        y = act_empty(rows, C, config.compute_dtype, x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        call('fw_layernorm_fwd', dt(y.dtype), x, x.stride(0), gamma, beta, y, y.stride(0), mean, rstd, rows, C, 1e-5)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.beta = beta
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dg, rg = _grad_target(gamma)
+        db, rb = _grad_target(ctx.beta)
+        if dy is None:
+            return dres, None, None
+        dx = ops.layernorm_bwd(aligned(dy), x, gamma, mean, rstd, dg, db, dres=dres)
+        return dx, rg, rb
 
 
 def linear(x, weight, bias=None, residual=None, rowscale=None, rows_per_scale=1, x_pre=None, gelu_out=False, out_f32=False):
@@ -329,8 +357,7 @@ class DownsampleFn(torch.autograd.Function):
         col = ops.im2col4(x, B, H, W, config.compute_dtype)
         dwk = _zeros((Co, 16 * C), x.device)
         db, rb = _grad_target(ctx.bias)
-        ops.gemm(g, col, Co, 16 * C, Mo, x_trans=True, w_trans=True, out=dwk, accumulate=True,
-                 splitk=ops.pick_splitk(Co, 16 * C, Mo, g.dtype), xsum=db)
+        ops.wgrad(g, col, Co, 16 * C, Mo, dwk, db)
         dw, rw = _grad_target(weight, (Co, C, 16))
         ops.permute3(dwk, dw, (Co, 16, C), (16 * C, 1, 16), accumulate=True)
         del col
@@ -365,8 +392,7 @@ class UpsampleCatFn(torch.autograd.Function):
         dg = ops.pixel_unshuffle(dcat[:, :Cout], B, H, W, Cout, config.compute_dtype)
         xq = ops.cast_rows(x, config.compute_dtype) if config.compute_dtype != torch.float32 else x
         dwt = _zeros((4 * Cout, Cin), x.device)
-        ops.gemm(dg, xq, 4 * Cout, Cin, M, x_trans=True, w_trans=True, out=dwt, accumulate=True,
-                 splitk=ops.pick_splitk(4 * Cout, Cin, M, dg.dtype))
+        ops.wgrad(dg, xq, 4 * Cout, Cin, M, dwt)
         dw, rw = _grad_target(weight, (Cin, Cout, 4))
         ops.permute3(dwt, dw, (4, Cout, Cin), (1, 4, Cout * 4), accumulate=True)
         dx = ops.gemm(dg, shadow(weight, 'convT2'), M, Cin, 4 * Cout, w_trans=True, out_dtype=torch.float32)

@@ -202,12 +202,12 @@ class DecLeWinTransformerBlock(nn.Module):
         rows, C = x.shape
         h = _tokens_hw(rows, batch)
         dp = Fn.droppath_scale(self._name, batch, self.drop_path_rate, self.training, x.device)
-        xn = Fn.LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias)
+        x, xn = Fn.LnResFn.apply(x, self.norm1.weight, self.norm1.bias)
         qkv = self.attn.qkv(xn)
         geo = (C, batch, h, h, self.num_heads, 1, 0, self.shift_size, self.attn.lfs_mode if coef is not None else 0)
         o = Fn.WindowAttnFn.apply(qkv, self.attn.relative_position_bias_table.unsqueeze(0), coef, geo)
         x = Fn.linear(o, self.attn.proj.weight, self.attn.proj.bias, residual=x, rowscale=dp, rows_per_scale=h * h)
-        xn2 = Fn.LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias)
+        x, xn2 = Fn.LnResFn.apply(x, self.norm2.weight, self.norm2.bias)
         return self.mlp.run(xn2, x, dp, batch)
 
 
@@ -406,7 +406,7 @@ class EncLeWinTransformerBlock(nn.Module):
         rows, C = x.shape
         h = _tokens_hw(rows, nimg)
         dp = Fn.droppath_scale(self._name, nimg, self.drop_path_rate, self.training, x.device)
-        xn = Fn.LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias)
+        x, xn = Fn.LnResFn.apply(x, self.norm1.weight, self.norm1.bias)
         if self.encoder_msa_type == 'origin':
             geo = (C, nimg, h, h, self.num_heads, 1, 0, self.shift_size, 0)
             o = Fn.WindowAttnFn.apply(self.attn.qkv(xn), self.attn.tables(), None, geo)
@@ -419,7 +419,7 @@ class EncLeWinTransformerBlock(nn.Module):
             a = self.attn_inter
             o = Fn.WindowAttnFn.apply(a.qkv(y1), a.tables(), None, (C, B, h, h, self.num_heads, self.L, 1, self.shift_size, 0))
             x = Fn.linear(o, a.proj.weight, a.proj.bias, residual=x, rowscale=dp, rows_per_scale=h * h)
-        xn2 = Fn.LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias)
+        x, xn2 = Fn.LnResFn.apply(x, self.norm2.weight, self.norm2.bias)
         return self.mlp.run(xn2, x, dp, nimg)
 
 

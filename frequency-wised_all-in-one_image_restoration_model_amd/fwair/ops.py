@@ -19,7 +19,7 @@ def empty(rows, cols, dtype, device):
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(x, w, M, N, K, *, x_trans=False, w_trans=False, x_op=0, w_op=0, out=None, out_dtype=None, bias=None,
          act=0, slope=0.0, aux=None, rowscale=None, rows_per_scale=1, residual=None, accumulate=False, splitk=1,
-         alpha=1.0, out_gelu=None, xsum=None):
+         alpha=1.0, out_gelu=None, xsum=None, c_zstride=0, xsum_zstride=0):
     """C[M,N] = epi(alpha * X W^T).  x: [M,K] (or [K,M] when x_trans), w: [N,K] (or [K,N] when w_trans)."""
     assert x.dtype == w.dtype
     if out is None:
@@ -28,7 +28,7 @@ def gemm(x, w, M, N, K, *, x_trans=False, w_trans=False, x_op=0, w_op=0, out=Non
     call('fw_gemm', dt(x.dtype), x, _ld(x), int(x_trans), x_op, w, _ld(w), int(w_trans), w_op, out, _ld(out), out_f32,
          int(accumulate), M, N, K, float(alpha), bias, act, float(slope), aux, _ld(aux) if aux is not None else 0,
          rowscale, rows_per_scale, residual, _ld(residual) if residual is not None else 0, splitk,
-         out_gelu, _ld(out_gelu) if out_gelu is not None else 0, xsum)
+         out_gelu, _ld(out_gelu) if out_gelu is not None else 0, xsum, c_zstride, xsum_zstride)
     return out
 
 
@@ -38,7 +38,27 @@ def pick_splitk(M, N, K, dtype):
     tiles = ((M + 127) // 128) * ((N + (63 if N <= 64 else 127)) // (64 if N <= 64 else 128))
     steps = (K + kt - 1) // kt
     want = max(1, 1024 // tiles)
-    return int(max(1, min(want, steps // 4 if steps >= 8 else 1)))
+    sk = int(max(1, min(want, steps // 4 if steps >= 8 else 1)))
+    while sk > 1 and sk * M * N * 4 > (256 << 20):          # keep the partial-tile slab under 256 MB
+        sk //= 2
+    return sk
+
+
+def wgrad(g, x, n, k, m, dw, db=None):
+    """dw[n][k] += sum_m g[m][n] x[m][k];  db[n] += sum_m g[m][n].  Large reductions are split over K into a slab of
+    partial tiles (plain stores) that fw_slab_reduce folds -- no same-address atomics."""
+    sk = pick_splitk(n, k, m, g.dtype)
+    if sk == 1:
+        gemm(g, x, n, k, m, x_trans=True, w_trans=True, out=dw, accumulate=True, xsum=db)
+        return
+    S = n * k + (n + 3) // 4 * 4
+    slab = torch.empty((sk, S), dtype=torch.float32, device=g.device)
+    cview = slab[0, :n * k].view(n, k)
+    xs = slab[0, n * k:] if db is not None else None
+    gemm(g, x, n, k, m, x_trans=True, w_trans=True, out=cview, splitk=sk, xsum=xs, c_zstride=S, xsum_zstride=S if db is not None else 0)
+    call('fw_slab_reduce', slab, sk, n * k, S, dw, 1)
+    if db is not None:
+        call('fw_slab_reduce', xs, sk, n, S, db, 1)
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm

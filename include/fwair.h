@@ -34,7 +34,9 @@ extern "C" {
 int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op, const void* W, long ldw, int w_trans, int w_op,
             void* C, long ldc, int out_f32, int accumulate, int M, int N, int K, float alpha, const float* bias, int act,
             float slope, const void* aux, long ldaux, const float* rowscale, int rows_per_scale, const float* residual,
-            long ldr, int splitk, void* C2, long ldc2, float* xsum, void* stream);
+            long ldr, int splitk, void* C2, long ldc2, float* xsum, long c_zstride, long xsum_zstride, void* stream);
+/* split-K without atomics: slice z stores its partial tile at C + z*c_zstride (and xsum + z*xsum_zstride); this sums the slices */
+int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, void* stream);
 
 /* ---- LayerNorm over the f32 stream -> T (decoder_Uformer.py:567,594,666,744; encoder_Uformer.py:941) -- */
 int fw_layernorm_fwd(int dtype, const float* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,

@@ -64,9 +64,10 @@ def test_train_step_fp32(variant):
     rel = ((norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(floor))
     worst = int(rel.argmax())
     assert rel.max() < 5e-3, f'grad norm of {names[worst]}: {norms[worst]:.6e} vs {g["grad_norms"][worst]:.6e}'
+    gmax = float(g['grad_norms'].max())
     for key, val in g.items():
-        if key.startswith('g.'):
-            close(params[key[2:]].grad, val, 5e-3, key)
+        if key.startswith('g.'):     # tensors that are ~0 by cancellation (1e-9 lambda-MLP grads) only see float-atomic ordering noise
+            close(params[key[2:]].grad, val, 5e-3 if float(val.norm()) > 1e-6 * gmax else 5e-2, key)
     close(net.E.E.queue, g['queue_after'], 1e-4, 'queue')
     assert int(net.E.E.queue_ptr) == int(g['queue_ptr_after'])
     close(net.E.E.encoder_q.norm[0][0].running_mean, g['bn_q0_running_mean'], 1e-3, 'bn running mean (q)')

@@ -122,6 +122,11 @@ def test_gemm_tn_dw(dtype, M, N, K, split):
     ops().gemm(pad(dy), pad(x), M, N, K, x_trans=True, w_trans=True, out=out, accumulate=True, splitk=split, xsum=xsum)
     close(out, dy.t() @ x, TOL[dtype], 'TN')
     close(xsum, dy.sum(0), 1e-4, 'fused column sums (bias gradient)')
+    # the production path: slab of partial tiles + fw_slab_reduce, accumulating into pre-filled targets
+    dw, db = torch.ones(M, N, device=DEV), torch.ones(M, device=DEV)
+    ops().wgrad(pad(dy), pad(x), M, N, K, dw, db)
+    close(dw - 1, dy.t() @ x, TOL[dtype], 'wgrad (slab split-K)')
+    close(db - 1, dy.sum(0), 1e-4, 'wgrad bias')
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm

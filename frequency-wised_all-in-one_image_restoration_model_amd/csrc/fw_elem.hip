@@ -77,119 +77,147 @@ __global__ void permute3_kernel(const TI* __restrict__ in, TO* __restrict__ out,
 // ------------------------------------------------------------------------------------------------
 // LeFF depthwise 3x3 (net/utils/leff.py:104-111).  Pre- and post-activation tensors are both kept
 // (h = pre, g = GELU(h)) so no erf is ever recomputed per tap:
-//   fwd : h2 = dwconv3x3(g1) + bias ;  g2 = GELU(h2)
-//   bwd : dh1 = GELU'(h1) * convT(dh2, w) ;  dw[c][tap] += sum_t g1[t+tap] dh2[t] ;  dbias[c] += sum_t dh2[t]
+//   fwd      : h2 = dwconv3x3(g1) + bias ;  g2 = GELU(h2)
+//   bwd data : dh1 = GELU'(h1) * convT(dh2, w)
+//   bwd wgt  : dw[c][tap] += sum_t g1[t+tap] dh2[t] ;  dbias[c] += sum_t dh2[t]
+// Weights (and their gradient) are TAP-MAJOR f32 [9][C] so a lane's E weights of one tap are one vector load.
+// A thread owns a strip of 8 consecutive pixels of one row and one 16-byte channel vector: the 72 weights are
+// loaded once per strip and the 3 x 10 input vectors of the strip are each loaded once (3.75 loads per output
+// instead of 9), with the 16-byte accesses of neighbouring threads contiguous along channels.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void dwconv_fwd_kernel(const T* __restrict__ g1, long ld1, const float* __restrict__ w, const float* __restrict__ bias,
-                                  T* __restrict__ h2, T* __restrict__ g2, long ld2, int B, int H, int W, int C) {
+constexpr int SX = 8;     // strip length (W is a multiple of 8 everywhere in the model)
+
+// MODE 0: forward (writes out = conv + bias and out2 = GELU(out));  MODE 1: data gradient (flipped taps, times GELU'(pre))
+template <typename T, int MODE>
+__global__ void dwconv_strip_kernel(const T* __restrict__ in, long ldi, const float* __restrict__ w, const float* __restrict__ bias,
+                                    const T* __restrict__ pre, T* __restrict__ out, T* __restrict__ out2, long ldo, int B, int H, int W, int C) {
     constexpr int E = TT<T>::E16;
-    const int nv = C / E;
-    const long total = (long)B * H * W * nv;
+    const int nv = C / E, ns = W / SX;
+    const long total = (long)B * H * ns * nv;
     for (long i = gtid(); i < total; i += gstride()) {
-        const int v = (int)(i % nv); const long tok = i / nv;
-        const int x = (int)(tok % W); const int y = (int)((tok / W) % H); const long b = tok / ((long)W * H);
-        const int c0 = v * E;
-        float acc[E], wr[E][9];
+        const int v = (int)(i % nv); long t = i / nv;
+        const int sx = (int)(t % ns); t /= ns;
+        const int y = (int)(t % H); const long b = t / H;
+        const int c0 = v * E, x0 = sx * SX;
+        float wr[E][9], acc[SX][E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            acc[e] = bias[c0 + e];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) wr[e][t] = w[(c0 + e) * 9 + t];
+            for (int k = 0; k < 9; ++k) wr[e][k] = w[(MODE == 0 ? k : 8 - k) * C + c0 + e];      // tap-major weights: contiguous per lane
+            const float b0 = MODE == 0 ? bias[c0 + e] : 0.f;
+#pragma unroll
+            for (int o = 0; o < SX; ++o) acc[o][e] = b0;
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int yy = y + ky - 1;
             if (yy < 0 || yy >= H) continue;
+            const T* row = in + ((b * H + yy) * W) * ldi + c0;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int xx = x + kx - 1;
+            for (int cx = -1; cx <= SX; ++cx) {
+                const int xx = x0 + cx;
                 if (xx < 0 || xx >= W) continue;
                 float f[E];
-                ldvec<T>(g1 + ((b * H + yy) * W + xx) * ld1 + c0, f);
+                ldvec<T>(row + (long)xx * ldi, f);
 #pragma unroll
-                for (int e = 0; e < E; ++e) acc[e] += f[e] * wr[e][ky * 3 + kx];
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int o = cx - kx + 1;
+                    if (o >= 0 && o < SX) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) acc[o][e] += f[e] * wr[e][ky * 3 + kx];
+                    }
+                }
             }
         }
-        stvec<T>(h2 + tok * ld2 + c0, acc);
+        const long tok0 = (b * H + y) * W + x0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) acc[e] = gelu_f(acc[e]);
-        stvec<T>(g2 + tok * ld2 + c0, acc);
+        for (int o = 0; o < SX; ++o) {
+            if (MODE == 0) {
+                stvec<T>(out + (tok0 + o) * ldo + c0, acc[o]);
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[o][e] = gelu_f(acc[o][e]);
+                stvec<T>(out2 + (tok0 + o) * ldo + c0, acc[o]);
+            } else {
+                float hc[E];
+                ldvec<T>(pre + (tok0 + o) * ldi + c0, hc);
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[o][e] *= gelu_grad_f(hc[e]);
+                stvec<T>(out + (tok0 + o) * ldo + c0, acc[o]);
+            }
+        }
     }
 }
 
-// block = 32 token stripes x 8 channel vectors; a thread walks STRIPE consecutive tokens of one vector with its
-// weight-gradient partials in registers; partials are reduced over the block's 32 stripes (shuffles + LDS) before ONE
-// atomic per (channel, tap) and block -- every block of a layer hits the same few hundred words otherwise.
-template <typename T, int STRIPE>
-__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ dh2, long ldg, const T* __restrict__ g1, const T* __restrict__ h1,
-                                                         long ld1, const float* __restrict__ w, T* __restrict__ dh1, long ldo,
-                                                         float* __restrict__ dw, float* __restrict__ dbias, int B, int H, int W, int C) {
+// weight / bias gradient.  block = 32 strip-groups x 8 channel vectors; a thread walks NSTRIP consecutive strips with its
+// 10 x E partial sums in registers; partials are reduced over the block (shuffles + LDS) before ONE atomic per word.
+template <typename T, int NSTRIP>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dh2, long ldg, const T* __restrict__ g1, long ld1,
+                                                           float* __restrict__ dw, float* __restrict__ dbias, int B, int H, int W, int C) {
     constexpr int E = TT<T>::E16;
     __shared__ float red[8 * E * 10];
-    const int nv = C / E;
+    const int nv = C / E, ns = W / SX;
     const int nvg = (nv + 7) / 8;
-    const long ntok = (long)B * H * W;
+    const long nstrips = (long)B * H * ns;
     const int vl = threadIdx.x & 7, sl = threadIdx.x >> 3;
     const int v = (blockIdx.x % nvg) * 8 + vl;
-    const long st = (long)(blockIdx.x / nvg) * 32 + sl;
+    const long s0 = ((long)(blockIdx.x / nvg) * 32 + sl) * NSTRIP;
     const bool live = v < nv;
     const int c0 = (live ? v : 0) * E;
     for (int i = threadIdx.x; i < 8 * E * 10; i += 256) red[i] = 0.f;
-    float wr[E][9], gw[E][10];
+    float gw[10][E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
+    for (int k = 0; k < 10; ++k)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) { wr[e][t] = w[(c0 + e) * 9 + t]; gw[e][t] = 0.f; }
-        gw[e][9] = 0.f;
-    }
+        for (int e = 0; e < E; ++e) gw[k][e] = 0.f;
     if (live)
-        for (long tok = st * STRIPE; tok < ntok && tok < (st + 1) * STRIPE; ++tok) {
-            const int x = (int)(tok % W); const int y = (int)((tok / W) % H); const long b = tok / ((long)W * H);
-            float g0[E], hc[E], din[E];
-            ldvec<T>(dh2 + tok * ldg + c0, g0);
-            ldvec<T>(h1 + tok * ld1 + c0, hc);
+        for (long s = s0; s < nstrips && s < s0 + NSTRIP; ++s) {
+            const int sx = (int)(s % ns); const int y = (int)((s / ns) % H); const long b = s / ((long)ns * H);
+            const int x0 = sx * SX;
+            float d[SX][E];
+            const T* drow = dh2 + ((b * H + y) * W + x0) * ldg + c0;
 #pragma unroll
-            for (int e = 0; e < E; ++e) { gw[e][9] += g0[e]; din[e] = 0.f; }
+            for (int o = 0; o < SX; ++o) {
+                ldvec<T>(drow + (long)o * ldg, d[o]);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+                for (int e = 0; e < E; ++e) gw[9][e] += d[o][e];
+            }
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int yy = y + ky - 1, xx = x + kx - 1;          // weight gradient: output t x input t + (ky-1, kx-1)
-                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                        float f[E];
-                        ldvec<T>(g1 + ((b * H + yy) * W + xx) * ld1 + c0, f);
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = y + ky - 1;
+                if (yy < 0 || yy >= H) continue;
+                const T* row = g1 + ((b * H + yy) * W) * ld1 + c0;
 #pragma unroll
-                        for (int e = 0; e < E; ++e) gw[e][ky * 3 + kx] += f[e] * g0[e];
-                    }
-                    const int yo = y - ky + 1, xo = x - kx + 1;          // data gradient: input t <- w[tap] * dh2[t - (ky-1, kx-1)]
-                    if (yo >= 0 && yo < H && xo >= 0 && xo < W) {
-                        float f[E];
-                        ldvec<T>(dh2 + ((b * H + yo) * W + xo) * ldg + c0, f);
+                for (int cx = -1; cx <= SX; ++cx) {
+                    const int xx = x0 + cx;
+                    if (xx < 0 || xx >= W) continue;
+                    float f[E];
+                    ldvec<T>(row + (long)xx * ld1, f);
 #pragma unroll
-                        for (int e = 0; e < E; ++e) din[e] += wr[e][ky * 3 + kx] * f[e];
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int o = cx - kx + 1;
+                        if (o >= 0 && o < SX) {
+#pragma unroll
+                            for (int e = 0; e < E; ++e) gw[ky * 3 + kx][e] += f[e] * d[o][e];
+                        }
                     }
                 }
-#pragma unroll
-            for (int e = 0; e < E; ++e) din[e] *= gelu_grad_f(hc[e]);
-            stvec<T>(dh1 + tok * ldo + c0, din);
+            }
         }
     __syncthreads();
-    // reduce over the 8 stripes of this wave (lanes with equal vl), then over the 4 waves through LDS
 #pragma unroll
-    for (int e = 0; e < E; ++e)
+    for (int k = 0; k < 10; ++k)
 #pragma unroll
-        for (int t = 0; t < 10; ++t) {
-            float s = gw[e][t];
+        for (int e = 0; e < E; ++e) {
+            float s = gw[k][e];
             s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-            if ((threadIdx.x & 63) < 8) atomicAdd(&red[(vl * E + e) * 10 + t], s);
+            if ((threadIdx.x & 63) < 8) atomicAdd(&red[(vl * E + e) * 10 + k], s);
         }
     __syncthreads();
     for (int i = threadIdx.x; i < 8 * E * 10; i += 256) {
-        const int t = i % 10, ce = i / 10;
+        const int k = i % 10, ce = i / 10;
         const int c = (blockIdx.x % nvg) * 8 * E + ce;
         if (c < C) {
-            if (t < 9) atomicAdd(dw + c * 9 + t, red[i]);
+            if (k < 9) atomicAdd(dw + (long)k * C + c, red[i]);                       // tap-major, like the weights
             else atomicAdd(dbias + c, red[i]);
         }
     }
@@ -295,23 +323,30 @@ __global__ void colsum_t_kernel(const T* __restrict__ x, long ldx, float* __rest
 // ------------------------------------------------------------------------------------------------
 // InputProj: 3x3 conv 3 -> C + LeakyReLU(0.01) on an NCHW f32 image  (decoder_Uformer.py:453-472)
 // ------------------------------------------------------------------------------------------------
-__global__ void inproj_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
-                                  float* __restrict__ out, long ldo, int B, int H, int W, int C, float slope) {
+__global__ __launch_bounds__(256) void inproj_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ out, long ldo, int B, int H, int W, int C, float slope) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];         // tap-major weights [27][C] + bias [C]
+    for (int i = threadIdx.x; i < C * 27; i += 256) sm[(i % 27) * C + i / 27] = w[i];
+    for (int i = threadIdx.x; i < C; i += 256) sm[27 * C + i] = bias[i];
+    __syncthreads();
     const int c4n = C >> 2;
     const long total = (long)B * H * W * c4n;
     for (long i = gtid(); i < total; i += gstride()) {
         const int c = (int)(i % c4n) * 4; const long tok = i / c4n;
         const int x = (int)(tok % W); const int y = (int)((tok / W) % H); const long b = tok / ((long)W * H);
-        f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c);
+        f32x4 acc = *reinterpret_cast<const f32x4*>(sm + 27 * C + c);
+#pragma unroll
         for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int yy = y + ky - 1;
                 if (yy < 0 || yy >= H) continue;
+#pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int xx = x + kx - 1;
                     if (xx < 0 || xx >= W) continue;
                     const float p = img[((b * 3 + ci) * H + yy) * W + xx];
-                    for (int e = 0; e < 4; ++e) acc[e] += p * w[((c + e) * 3 + ci) * 9 + ky * 3 + kx];
+                    acc += *reinterpret_cast<const f32x4*>(sm + (ci * 9 + ky * 3 + kx) * C + c) * p;
                 }
             }
         for (int e = 0; e < 4; ++e) acc[e] = lrelu_f(acc[e], slope);
@@ -360,12 +395,15 @@ __global__ __launch_bounds__(256) void inproj_bwd_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // OutputProj: 3x3 conv C -> 3 on tokens, + global residual, NCHW f32 out  (decoder_Uformer.py:476-499,1171)
 // ------------------------------------------------------------------------------------------------
-__global__ void outproj_fwd_kernel(const float* __restrict__ fea, long ldf, const float* __restrict__ w, const float* __restrict__ bias,
-                                   const float* __restrict__ img, float* __restrict__ out, int B, int H, int W, int C) {
+__global__ __launch_bounds__(256) void outproj_fwd_kernel(const float* __restrict__ fea, long ldf, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const float* __restrict__ img, float* __restrict__ out, int B, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];         // weights as [tap][co][C]
+    for (int i = threadIdx.x; i < 3 * C * 9; i += 256) { const int tap = i % 9, cc = (i / 9) % C, co = i / (9 * C); sm[(tap * 3 + co) * C + cc] = w[i]; }
+    __syncthreads();
     const long total = (long)B * H * W;
     for (long tok = gtid(); tok < total; tok += gstride()) {
         const int x = (int)(tok % W); const int y = (int)((tok / W) % H); const long b = tok / ((long)W * H);
-        float a0 = bias[0], a1 = bias[1], a2 = bias[2];
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
         for (int ky = 0; ky < 3; ++ky) {
             const int yy = y + ky - 1;
             if (yy < 0 || yy >= H) continue;
@@ -373,42 +411,45 @@ __global__ void outproj_fwd_kernel(const float* __restrict__ fea, long ldf, cons
                 const int xx = x + kx - 1;
                 if (xx < 0 || xx >= W) continue;
                 const float* f = fea + ((b * H + yy) * W + xx) * ldf;
-                const int tap = ky * 3 + kx;
+                const float* wt = sm + (ky * 3 + kx) * 3 * C;
                 for (int c = 0; c < C; c += 4) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(f + c);
-                    for (int e = 0; e < 4; ++e) {
-                        a0 += v[e] * w[(0 * C + c + e) * 9 + tap];
-                        a1 += v[e] * w[(1 * C + c + e) * 9 + tap];
-                        a2 += v[e] * w[(2 * C + c + e) * 9 + tap];
-                    }
+                    a0 += v * *reinterpret_cast<const f32x4*>(wt + c);
+                    a1 += v * *reinterpret_cast<const f32x4*>(wt + C + c);
+                    a2 += v * *reinterpret_cast<const f32x4*>(wt + 2 * C + c);
                 }
             }
         }
         const long p = (b * 3 * H + y) * W + x;
-        out[p] = a0 + (img ? img[p] : 0.f);
-        out[p + (long)H * W] = a1 + (img ? img[p + (long)H * W] : 0.f);
-        out[p + 2L * H * W] = a2 + (img ? img[p + 2L * H * W] : 0.f);
+        const long hw = (long)H * W;
+        out[p] = bias[0] + a0[0] + a0[1] + a0[2] + a0[3] + (img ? img[p] : 0.f);
+        out[p + hw] = bias[1] + a1[0] + a1[1] + a1[2] + a1[3] + (img ? img[p + hw] : 0.f);
+        out[p + 2 * hw] = bias[2] + a2[0] + a2[1] + a2[2] + a2[3] + (img ? img[p + 2 * hw] : 0.f);
     }
 }
 // dfea[tok][c] = sum_{co,tap} dout[co][tok - tap] w[co][c][tap]
-__global__ void outproj_bwd_data_kernel(const float* __restrict__ dout, const float* __restrict__ w, float* __restrict__ dfea, long ldf,
-                                        int B, int H, int W, int C) {
+__global__ __launch_bounds__(256) void outproj_bwd_data_kernel(const float* __restrict__ dout, const float* __restrict__ w, float* __restrict__ dfea, long ldf,
+                                                               int B, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];         // weights as [tap][co][C]
+    for (int i = threadIdx.x; i < 3 * C * 9; i += 256) { const int tap = i % 9, cc = (i / 9) % C, co = i / (9 * C); sm[(tap * 3 + co) * C + cc] = w[i]; }
+    __syncthreads();
     const int c4n = C >> 2;
     const long total = (long)B * H * W * c4n;
     for (long i = gtid(); i < total; i += gstride()) {
         const int c = (int)(i % c4n) * 4; const long tok = i / c4n;
         const int x = (int)(tok % W); const int y = (int)((tok / W) % H); const long b = tok / ((long)W * H);
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int yo = y - ky + 1;
             if (yo < 0 || yo >= H) continue;
+#pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int xo = x - kx + 1;
                 if (xo < 0 || xo >= W) continue;
-                for (int co = 0; co < 3; ++co) {
-                    const float d = dout[((b * 3 + co) * H + yo) * W + xo];
-                    for (int e = 0; e < 4; ++e) acc[e] += d * w[(co * C + c + e) * 9 + ky * 3 + kx];
-                }
+#pragma unroll
+                for (int co = 0; co < 3; ++co)
+                    acc += *reinterpret_cast<const f32x4*>(sm + ((ky * 3 + kx) * 3 + co) * C + c) * dout[((b * 3 + co) * H + yo) * W + xo];
             }
         }
         *reinterpret_cast<f32x4*>(dfea + tok * ldf + c) = acc;
@@ -521,23 +562,25 @@ template <typename T>
 __global__ void lrelu_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long n, float slope) {
     for (long i = gtid(); i < n; i += gstride()) dx[i] = TT<T>::ld(dy + i) * (x[i] > 0.f ? 1.f : slope);
 }
-// dst[i] (+)= sum_z slab[z*zstride + i]: the reduction step of a split-K GEMM (replaces thousands of same-address atomics)
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long n, long zstride, float* __restrict__ dst, int accumulate, int zper) {
+// dst[i] (+)= sum_z slab[z*zstride + i]: the reduction step of a split-K GEMM (replaces thousands of same-address atomics).
+// Two destination segments in one launch: [0, n) -> dst, [off2, off2 + n2) -> dst2 (weight and bias gradient of one GEMM).
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long n, long zstride, float* __restrict__ dst, int accumulate, int zper,
+                                   float* __restrict__ dst2, long off2, long n2) {
     const long i4 = gtid();
-    if (i4 * 4 >= n) return;
+    const long end = dst2 ? off2 + n2 : n;
+    if (i4 * 4 >= end) return;
     const int z0 = blockIdx.y * zper, z1 = min(nz, z0 + zper);
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (i4 * 4 + 3 < n) {
-        for (int z = z0; z < z1; ++z) s += *reinterpret_cast<const f32x4*>(slab + (long)z * zstride + i4 * 4);
-    } else {
-        for (int z = z0; z < z1; ++z)
-            for (int e = 0; e < 4; ++e) if (i4 * 4 + e < n) s[e] += slab[(long)z * zstride + i4 * 4 + e];
-    }
+    for (int z = z0; z < z1; ++z) s += *reinterpret_cast<const f32x4*>(slab + (long)z * zstride + i4 * 4);   // rows are padded to 4
     for (int e = 0; e < 4; ++e) {
-        if (i4 * 4 + e >= n) break;
-        if (gridDim.y > 1) atomicAdd(dst + i4 * 4 + e, s[e]);        // <= nz/zper adders per address
-        else if (accumulate) dst[i4 * 4 + e] += s[e];
-        else dst[i4 * 4 + e] = s[e];
+        const long i = i4 * 4 + e;
+        float* d = nullptr;
+        if (i < n) d = dst + i;
+        else if (dst2 && i >= off2 && i < off2 + n2) d = dst2 + (i - off2);
+        if (!d) continue;
+        if (gridDim.y > 1) atomicAdd(d, s[e]);        // <= nz/zper adders per address
+        else if (accumulate) *d += s[e];
+        else *d = s[e];
     }
 }
 __global__ void fill_kernel(float* __restrict__ p, long n, float v) {
@@ -587,25 +630,31 @@ extern "C" int fw_permute3(int in_dtype, int out_dtype, const void* in, void* ou
 extern "C" int fw_dwconv_fwd(int dtype, const void* g1, long ld1, const float* w, const float* bias, void* h2, void* g2, long ld2,
                              int B, int H, int W, int C, void* stream) {
     const int e = dtype == FW_DT_BF16 ? 8 : 4;
-    FW_CHECK_ARG(g1 && w && bias && h2 && g2 && C % e == 0 && ld1 % e == 0 && ld2 % e == 0);
-    const long n = (long)B * H * W * (C / e);
-    if (dtype == FW_DT_BF16) LAUNCH((dwconv_fwd_kernel<bf16raw>), n, (const bf16raw*)g1, ld1, w, bias, (bf16raw*)h2, (bf16raw*)g2, ld2, B, H, W, C);
-    LAUNCH((dwconv_fwd_kernel<float>), n, (const float*)g1, ld1, w, bias, (float*)h2, (float*)g2, ld2, B, H, W, C);
+    FW_CHECK_ARG(g1 && w && bias && h2 && g2 && C % e == 0 && ld1 % e == 0 && ld2 % e == 0 && W % SX == 0);
+    const long n = (long)B * H * (W / SX) * (C / e);
+    if (dtype == FW_DT_BF16)
+        LAUNCH((dwconv_strip_kernel<bf16raw, 0>), n, (const bf16raw*)g1, ld1, w, bias, (const bf16raw*)nullptr, (bf16raw*)h2, (bf16raw*)g2, ld2, B, H, W, C);
+    LAUNCH((dwconv_strip_kernel<float, 0>), n, (const float*)g1, ld1, w, bias, (const float*)nullptr, (float*)h2, (float*)g2, ld2, B, H, W, C);
 }
 extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g1, const void* h1, long ld1, const float* w, void* dh1,
                              long ldo, float* dw, float* dbias, int B, int H, int W, int C, void* stream) {
     const int e = dtype == FW_DT_BF16 ? 8 : 4;
-    FW_CHECK_ARG(dh2 && g1 && h1 && w && dh1 && dw && dbias && C % e == 0 && ld1 % e == 0 && ldg % e == 0 && ldo % e == 0);
-    constexpr int STRIPE = 32;
+    FW_CHECK_ARG(dh2 && g1 && h1 && w && dh1 && dw && dbias && C % e == 0 && ld1 % e == 0 && ldg % e == 0 && ldo % e == 0 && W % SX == 0);
+    FW_CHECK_ARG(ldg == ld1);                      // the data-gradient strip kernel walks dh2 and h1 with one row stride
+    constexpr int NSTRIP = 8;
+    const long n = (long)B * H * (W / SX) * (C / e);
     const int nvg = (C / e + 7) / 8;
-    const long nsg = (((long)B * H * W + STRIPE - 1) / STRIPE + 31) / 32;
-    const dim3 grid((unsigned)(nsg * nvg));
-    if (dtype == FW_DT_BF16)
-        hipLaunchKernelGGL((dwconv_bwd_kernel<bf16raw, STRIPE>), grid, dim3(256), 0, ST, (const bf16raw*)dh2, ldg, (const bf16raw*)g1,
-                           (const bf16raw*)h1, ld1, w, (bf16raw*)dh1, ldo, dw, dbias, B, H, W, C);
-    else
-        hipLaunchKernelGGL((dwconv_bwd_kernel<float, STRIPE>), grid, dim3(256), 0, ST, (const float*)dh2, ldg, (const float*)g1,
-                           (const float*)h1, ld1, w, (float*)dh1, ldo, dw, dbias, B, H, W, C);
+    const long nsg = (((long)B * H * (W / SX) + NSTRIP - 1) / NSTRIP + 31) / 32;
+    const dim3 gridw((unsigned)(nsg * nvg));
+    if (dtype == FW_DT_BF16) {
+        hipLaunchKernelGGL((dwconv_strip_kernel<bf16raw, 1>), dim3(grid_for(n)), dim3(TPB), 0, ST, (const bf16raw*)dh2, ldg, w, (const float*)nullptr,
+                           (const bf16raw*)h1, (bf16raw*)dh1, (bf16raw*)nullptr, ldo, B, H, W, C);
+        hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16raw, NSTRIP>), gridw, dim3(256), 0, ST, (const bf16raw*)dh2, ldg, (const bf16raw*)g1, ld1, dw, dbias, B, H, W, C);
+    } else {
+        hipLaunchKernelGGL((dwconv_strip_kernel<float, 1>), dim3(grid_for(n)), dim3(TPB), 0, ST, (const float*)dh2, ldg, w, (const float*)nullptr,
+                           (const float*)h1, (float*)dh1, (float*)nullptr, ldo, B, H, W, C);
+        hipLaunchKernelGGL((dwconv_wgrad_kernel<float, NSTRIP>), gridw, dim3(256), 0, ST, (const float*)dh2, ldg, (const float*)g1, ld1, dw, dbias, B, H, W, C);
+    }
     FW_LAUNCH_RET();
 }
 extern "C" int fw_im2col4(int dtype, const float* x, long ldx, void* col, int B, int H, int W, int C, void* stream) {
@@ -647,7 +696,8 @@ extern "C" int fw_colsum(int x_dtype, const void* x, long ldx, float* out, long 
 extern "C" int fw_inproj_fwd(const float* img, const float* w, const float* bias, float* out, long ldo, int B, int H, int W, int C,
                              float slope, void* stream) {
     FW_CHECK_ARG(img && w && bias && out && C % 4 == 0 && ldo % 4 == 0);
-    LAUNCH(inproj_fwd_kernel, (long)B * H * W * (C / 4), img, w, bias, out, ldo, B, H, W, C, slope);
+    hipLaunchKernelGGL(inproj_fwd_kernel, dim3(grid_for((long)B * H * W * (C / 4), 2048)), dim3(TPB), (size_t)C * 28 * 4, ST, img, w, bias, out, ldo, B, H, W, C, slope);
+    FW_LAUNCH_RET();
 }
 extern "C" int fw_inproj_bwd(const float* img, const float* out, long ldo, const float* dy, long ldy, float* dw, float* db, int B,
                              int H, int W, int C, float slope, void* stream) {
@@ -660,12 +710,13 @@ extern "C" int fw_inproj_bwd(const float* img, const float* out, long ldo, const
 extern "C" int fw_outproj_fwd(const float* fea, long ldf, const float* w, const float* bias, const float* img, float* out, int B,
                               int H, int W, int C, void* stream) {
     FW_CHECK_ARG(fea && w && bias && out && C % 4 == 0 && ldf % 4 == 0);
-    LAUNCH(outproj_fwd_kernel, (long)B * H * W, fea, ldf, w, bias, img, out, B, H, W, C);
+    hipLaunchKernelGGL(outproj_fwd_kernel, dim3(grid_for((long)B * H * W, 2048)), dim3(TPB), (size_t)C * 27 * 4, ST, fea, ldf, w, bias, img, out, B, H, W, C);
+    FW_LAUNCH_RET();
 }
 extern "C" int fw_outproj_bwd(const float* dout, const float* fea, long ldf, const float* w, float* dfea, long lddf, float* dw,
                               float* db, int B, int H, int W, int C, void* stream) {
     FW_CHECK_ARG(dout && fea && w && dfea && dw && db && C % 4 == 0 && ldf % 4 == 0 && lddf % 4 == 0);
-    hipLaunchKernelGGL(outproj_bwd_data_kernel, dim3(grid_for((long)B * H * W * (C / 4))), dim3(TPB), 0, ST, dout, w, dfea, lddf, B, H, W, C);
+    hipLaunchKernelGGL(outproj_bwd_data_kernel, dim3(grid_for((long)B * H * W * (C / 4), 2048)), dim3(TPB), (size_t)C * 27 * 4, ST, dout, w, dfea, lddf, B, H, W, C);
     constexpr int STRIPE = 32;
     hipLaunchKernelGGL((outproj_bwd_w_kernel<STRIPE>), dim3(grid_for((((long)B * H * W + STRIPE - 1) / STRIPE) * C, 1024)), dim3(TPB),
                        (size_t)(C * 27 + 3) * 4, ST, dout, fea, ldf, dw, db, B, H, W, C);
@@ -709,12 +760,16 @@ extern "C" int fw_lrelu_bwd(int dtype, const void* dy, const float* x, float* dx
     LAUNCH((lrelu_bwd_kernel<float>), n, (const float*)dy, x, dx, n, slope);
 }
 // dst must be pre-initialised when accumulate != 0 or when nz > 64 (the z range is then split over blockIdx.y with atomics).
-extern "C" int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, void* stream) {
+// zstride and the segment [0, max(n, off2 + n2)) rounded up to 4 must lie inside every slab row.
+extern "C" int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, float* dst2, long off2, long n2,
+                              void* stream) {
     FW_CHECK_ARG(slab && dst && nz > 0 && n > 0 && zstride % 4 == 0 && ((uintptr_t)slab & 15) == 0);
     FW_CHECK_ARG(accumulate || nz <= 64);
+    FW_CHECK_ARG(!dst2 || (off2 >= n && n2 > 0 && off2 + n2 <= zstride));
     const int zper = 64;
-    dim3 grid((unsigned)((n / 4 + 1 + TPB - 1) / TPB), (unsigned)((nz + zper - 1) / zper));
-    hipLaunchKernelGGL(slab_reduce_kernel, grid, dim3(TPB), 0, ST, slab, nz, n, zstride, dst, accumulate, zper);
+    const long end = dst2 ? off2 + n2 : n;
+    dim3 grid((unsigned)(((end + 3) / 4 + TPB - 1) / TPB), (unsigned)((nz + zper - 1) / zper));
+    hipLaunchKernelGGL(slab_reduce_kernel, grid, dim3(TPB), 0, ST, slab, nz, n, zstride, dst, accumulate, zper, dst2, off2, n2);
     FW_LAUNCH_RET();
 }
 extern "C" int fw_fill(float* p, long n, float v, void* stream) {

@@ -310,8 +310,10 @@ class DwConvFn(torch.autograd.Function):
         C = h1.shape[1]
         h2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
         g2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
-        call('fw_dwconv_fwd', dt(h1.dtype), g1, g1.stride(0), weight, bias, h2, g2, h2.stride(0), B, H, W, C)
-        ctx.save_for_backward(h1, g1, weight)
+        wt = torch.empty((9, C), dtype=torch.float32, device=h1.device)          # tap-major copy of the [C,1,3,3] weight
+        ops.permute3(weight.detach().reshape(C, 9), wt, (1, C, 9), (0, 1, C))
+        call('fw_dwconv_fwd', dt(h1.dtype), g1, g1.stride(0), wt, bias, h2, g2, h2.stride(0), B, H, W, C)
+        ctx.save_for_backward(h1, g1, weight, wt)
         ctx.bias = bias
         ctx.geo = (B, H, W)
         ctx.mark_non_differentiable(g2)
@@ -319,14 +321,16 @@ class DwConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dh2, _):
-        h1, g1, weight = ctx.saved_tensors
+        h1, g1, weight, wt = ctx.saved_tensors
         B, H, W = ctx.geo
         C = h1.shape[1]
         dh2 = aligned(dh2)
-        dw, rw = _grad_target(weight, (C, 9))
+        dwt = _zeros((9, C), h1.device)
         db, rb = _grad_target(ctx.bias)
         dh1 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
-        call('fw_dwconv_bwd', dt(h1.dtype), dh2, dh2.stride(0), g1, h1, h1.stride(0), weight, dh1, dh1.stride(0), dw, db, B, H, W, C)
+        call('fw_dwconv_bwd', dt(h1.dtype), dh2, dh2.stride(0), g1, h1, h1.stride(0), wt, dh1, dh1.stride(0), dwt, db, B, H, W, C)
+        dw, rw = _grad_target(weight, (C, 9))
+        ops.permute3(dwt, dw, (1, 9, C), (0, 1, 9), accumulate=True)
         return dh1, None, (rw.view_as(weight) if rw is not None else None), rb, None, None, None
 
 

@@ -33,15 +33,13 @@ def gemm(x, w, M, N, K, *, x_trans=False, w_trans=False, x_op=0, w_op=0, out=Non
 
 
 def pick_splitk(M, N, K, dtype):
-    """Split the reduction so that a weight-gradient GEMM (small M x N, huge K) fills the chip."""
-    kt = 64 if dtype == torch.bfloat16 else 32
-    tiles = ((M + 127) // 128) * ((N + (63 if N <= 64 else 127)) // (64 if N <= 64 else 128))
-    steps = (K + kt - 1) // kt
-    want = max(1, 1024 // tiles)
-    sk = int(max(1, min(want, steps // 4 if steps >= 8 else 1)))
+    """Split factor of a weight-gradient GEMM (small M x N output, long reduction K = tokens).  Rule fitted to a sweep on
+    MI355X (tools/splitk_sweep.py): about 512 blocks in flight, at least 512 reduction rows (8 K-steps) per block."""
+    tiles = ((M + 127) // 128) * ((N + 63) // 64 if N <= 64 else (N + 127) // 128)
+    sk = max(1, min(512 // max(tiles, 1), K // 512))
     while sk > 1 and sk * M * N * 4 > (256 << 20):          # keep the partial-tile slab under 256 MB
         sk //= 2
-    return sk
+    return int(sk)
 
 
 def wgrad(g, x, n, k, m, dw, db=None):
@@ -51,14 +49,13 @@ def wgrad(g, x, n, k, m, dw, db=None):
     if sk == 1:
         gemm(g, x, n, k, m, x_trans=True, w_trans=True, out=dw, accumulate=True, xsum=db)
         return
-    S = n * k + (n + 3) // 4 * 4
+    nk = (n * k + 3) // 4 * 4
+    S = nk + (n + 3) // 4 * 4
     slab = torch.empty((sk, S), dtype=torch.float32, device=g.device)
     cview = slab[0, :n * k].view(n, k)
-    xs = slab[0, n * k:] if db is not None else None
+    xs = slab[0, nk:] if db is not None else None
     gemm(g, x, n, k, m, x_trans=True, w_trans=True, out=cview, splitk=sk, xsum=xs, c_zstride=S, xsum_zstride=S if db is not None else 0)
-    call('fw_slab_reduce', slab, sk, n * k, S, dw, 1)
-    if db is not None:
-        call('fw_slab_reduce', xs, sk, n, S, db, 1)
+    call('fw_slab_reduce', slab, sk, n * k, S, dw, 1, db, nk, n if db is not None else 0)
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
@@ -124,7 +121,7 @@ def rel_index(device):
 
 # ------------------------------------------------------------------------------------------------ LeFF dwconv
 def dwconv_fwd(g1, w, bias, B, H, W):
-    """-> (h2, g2 = GELU(h2))"""
+    """w: f32 tap-major [9, C].  -> (h2, g2 = GELU(h2))"""
     h2, g2 = torch.empty_like(g1), torch.empty_like(g1)
     call('fw_dwconv_fwd', dt(g1.dtype), g1, _ld(g1), w, bias, h2, g2, _ld(h2), B, H, W, g1.shape[1])
     return h2, g2

@@ -36,7 +36,8 @@ int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op, const voi
             float slope, const void* aux, long ldaux, const float* rowscale, int rows_per_scale, const float* residual,
             long ldr, int splitk, void* C2, long ldc2, float* xsum, long c_zstride, long xsum_zstride, void* stream);
 /* split-K without atomics: slice z stores its partial tile at C + z*c_zstride (and xsum + z*xsum_zstride); this sums the slices */
-int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, void* stream);
+int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, float* dst2, long off2, long n2,
+                   void* stream);
 
 /* ---- LayerNorm over the f32 stream -> T (decoder_Uformer.py:567,594,666,744; encoder_Uformer.py:941) -- */
 int fw_layernorm_fwd(int dtype, const float* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
@@ -66,7 +67,8 @@ int fw_attn_bwd(int dtype, int D, int nkt, int lfs, const void* q, const void* k
                 float* dcoef, int B, int H, int W, int heads, int L, int mode, int shift, float scale, void* stream);
 
 /* ---- LeFF depthwise 3x3 (net/utils/leff.py:104-111).  Both pre-activations (h) and GELU outputs (g) are kept:
- * fwd: h2 = dwconv(g1) + bias, g2 = GELU(h2);  bwd: dh1 = GELU'(h1) * convT(dh2), dw/dbias accumulated.  w: f32 [C][9]. */
+ * fwd: h2 = dwconv(g1) + bias, g2 = GELU(h2);  bwd: dh1 = GELU'(h1) * convT(dh2), dw/dbias accumulated.
+ * w and dw are TAP-MAJOR f32 [9][C] (the host permutes the [C,1,3,3] parameter / gradient). */
 int fw_dwconv_fwd(int dtype, const void* g1, long ld1, const float* w, const float* bias, void* h2, void* g2, long ld2, int B,
                   int H, int W, int C, void* stream);
 int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g1, const void* h1, long ld1, const float* w, void* dh1,

@@ -249,15 +249,16 @@ def test_dwconv(dtype):
     b = (rnd(C, seed=2) * 0.1).requires_grad_(True)
     g1 = q(F.gelu(h1.detach()), dtype)                       # the stored post-activation twin (rounded like the kernel stores it)
     ref = F.conv2d(F.gelu(h1).view(B, H, W, C).permute(0, 3, 1, 2), w, b, padding=1, groups=C).permute(0, 2, 3, 1).reshape(B * H * W, C)
-    h2, g2 = ops().dwconv_fwd(g1.to(DEV, dtype), w.detach().view(C, 9).to(DEV), b.detach().to(DEV), B, H, W)
+    wt = w.detach().view(C, 9).t().contiguous().to(DEV)                 # tap-major [9, C]
+    h2, g2 = ops().dwconv_fwd(g1.to(DEV, dtype), wt, b.detach().to(DEV), B, H, W)
     close(h2, ref, TOL[dtype], 'h2')
     close(g2, F.gelu(ref), TOL[dtype], 'g2')
     dh2 = q(rnd(B * H * W, C, seed=3), dtype)
     ref.backward(dh2)
-    dw, db = torch.zeros(C, 9, device=DEV), torch.zeros(C, device=DEV)
-    dh1 = ops().dwconv_bwd(dh2.to(DEV, dtype), g1.to(DEV, dtype), h1.detach().to(DEV, dtype), w.detach().view(C, 9).to(DEV), dw, db, B, H, W)
+    dw, db = torch.zeros(9, C, device=DEV), torch.zeros(C, device=DEV)
+    dh1 = ops().dwconv_bwd(dh2.to(DEV, dtype), g1.to(DEV, dtype), h1.detach().to(DEV, dtype), wt, dw, db, B, H, W)
     close(dh1, h1.grad, TOL[dtype] * 2, 'dh1')
-    close(dw, w.grad.view(C, 9), TOL[dtype] * 2, 'dw')
+    close(dw.t(), w.grad.view(C, 9), TOL[dtype] * 2, 'dw')
     close(db, b.grad, TOL[dtype] * 2, 'db')
 
 

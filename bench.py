@@ -97,6 +97,7 @@ def cpu_baseline(threads):
     import airnet_oracle as O
     from helpers import schema
     torch.set_num_threads(threads)
+    log(f'cpu baseline: oracle train steps on {threads} threads')
     B = 2
     opt = O.make_opt(batch_size=B)
     st = O.fill_state_seeded(schema('all3'))
@@ -114,11 +115,25 @@ def cpu_baseline(threads):
         loss.backward()
         optim.step()
         steps += 1
+        log(f'cpu baseline: step {steps} done at {time.time() - t0:.1f}s')
         if steps == 1:
             t0 = time.time()           # first step = warm-up (allocator, thread pools)
     dt = time.time() - t0
     return {'value': round(B * (steps - 1) / dt, 4), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'sample': f'{steps - 1} phase-2 train step(s) (fwd+bwd+Adam) of the CPU oracle, B={B}, 128x128, fp32, after 1 warm-up step'}
+
+
+def log(msg):
+    print(f'[bench] {msg}', file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """Cores this process may actually use (the GPU box gives one GPU a 16-core share of a much larger host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
 
 
 def main():
@@ -147,6 +162,7 @@ def main():
     clean, xq, xk = batch
     data = (xq, xk, clean)
 
+    log(f'model built on {dev}; warm-up / graph capture ...')
     graph_ok = not args.no_graph
     try:
         for _ in range(max(1, args.warmup)):
@@ -160,6 +176,7 @@ def main():
         for _ in range(max(1, args.warmup)):
             out = eng.step(*data)
     torch.cuda.synchronize()
+    log('warm-up done; timing ...')
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
@@ -175,6 +192,7 @@ def main():
         dt = float(t)
     loss = [float(v) for v in out]
     ips = args.batch * world * args.steps / dt
+    log(f'{ips:.1f} images/sec, {dt / args.steps * 1e3:.1f} ms/step')
 
     res = {
         'metric': 'training images/sec @128x128', 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
@@ -188,6 +206,7 @@ def main():
     peak = PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32_MFMA
     res['step_mfma_fraction'] = round(ips / world * FLOP_PER_IMAGE_STEP / peak, 5)
     if rank == 0 and world == 1 and not args.no_profile:
+        log('timing every GEMM launch of two eager steps with HIP events ...')
         agg, launches = gemm_profile(eng, data)
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         tot_t = sum(v[1] for v in agg.values())
@@ -199,7 +218,7 @@ def main():
                            'gemm_time_ms_per_step': round(tot_t / 2 * 1e3, 3),
                            'all_gemm_tflops': round(sum(x[0] for x in agg.values()) / tot_t / 1e12, 2)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res['cpu_baseline'] = cpu_baseline(os.cpu_count() or 1)
+        res['cpu_baseline'] = cpu_baseline(host_threads())
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -151,6 +151,26 @@ struct StageTrans {
     }
 };
 
+// GLDS: direct global -> LDS (global_load_lds_dwordx4), no VGPR round trip and no ds_write.  One wave-instruction fills
+// 8 rows x 128 B linearly (LDS address = wave-uniform base + lane*16), so the XOR slot swizzle is applied to the per-lane
+// SOURCE address: physical slot p of row r receives logical chunk p ^ sw(r).  Needs whole K steps and no load-op; rows past
+// the end are clamped (they only feed masked outputs).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+template <typename T, int ROWS>
+FW_DEV void glds_issue(const char* base, long ld, int row0, int rows_total, int kbyte0, char* tile) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int it = 0; it < ROWS / 32; ++it) {
+        const int R0 = (wave * (ROWS / 32) + it) * 8;
+        const int r = R0 + (lane >> 3), p = lane & 7;
+        int gr = row0 + r;
+        if (gr >= rows_total) gr = rows_total - 1;
+        const char* g = base + (long)gr * ld * TT<T>::SZ + kbyte0 + ((p ^ (swz(r) >> 4)) << 4);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)(tile + R0 * LDS_ROW), 16, 0, 0);
+    }
+}
+
 template <typename T, int ROWS> struct StageDirectAcc : StageDirect<T, ROWS> {
     FW_MEM void accum(float (&)[TT<T>::E16]) const {}
 };
@@ -172,7 +192,7 @@ FW_DEV uint4 frag_sw(const char* tile, int row0, int chunk) {
     return *reinterpret_cast<const uint4*>(tile + row * LDS_ROW + ((chunk * 64 + ((l >> 4) << 4)) ^ swz(row)));
 }
 
-template <typename T, int BN, bool XT, bool WT>
+template <typename T, int BN, bool XT, bool WT, bool GX, bool GW>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     constexpr int KT = 128 / TT<T>::SZ;                  // k elements per step
     constexpr int WM = (BN == 128) ? 4 : 2;              // m tiles (16) per wave
@@ -200,19 +220,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     for (int e = 0; e < TT<T>::E16; ++e) xsum[e] = 0.f;
     const bool do_xsum = XT && a.xsum != nullptr && blockIdx.y == 0;
     if (nsteps > 0) {
-        sx.fetch(a.X, a.ldx, m_blk, a.M, k_begin, k_end, a.x_op);
-        if (do_xsum) sx.accum(xsum);
-        sw.fetch(a.W, a.ldw, n_blk, a.N, k_begin, k_end, a.w_op);
-        sx.store(xs(0));
-        sw.store(ws(0));
+        if constexpr (GX) glds_issue<T, BM>(a.X, a.ldx, m_blk, a.M, k_begin * TT<T>::SZ, xs(0));
+        else { sx.fetch(a.X, a.ldx, m_blk, a.M, k_begin, k_end, a.x_op); if (do_xsum) sx.accum(xsum); }
+        if constexpr (GW) glds_issue<T, BN>(a.W, a.ldw, n_blk, a.N, k_begin * TT<T>::SZ, ws(0));
+        else sw.fetch(a.W, a.ldw, n_blk, a.N, k_begin, k_end, a.w_op);
+        if constexpr (!GX) sx.store(xs(0));
+        if constexpr (!GW) sw.store(ws(0));
     }
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
         if (s + 1 < nsteps) {
-            sx.fetch(a.X, a.ldx, m_blk, a.M, k_begin + (s + 1) * KT, k_end, a.x_op);
-            sw.fetch(a.W, a.ldw, n_blk, a.N, k_begin + (s + 1) * KT, k_end, a.w_op);
-            if (do_xsum) sx.accum(xsum);
+            if constexpr (GX) glds_issue<T, BM>(a.X, a.ldx, m_blk, a.M, (k_begin + (s + 1) * KT) * TT<T>::SZ, xs(cur ^ 1));
+            else { sx.fetch(a.X, a.ldx, m_blk, a.M, k_begin + (s + 1) * KT, k_end, a.x_op); if (do_xsum) sx.accum(xsum); }
+            if constexpr (GW) glds_issue<T, BN>(a.W, a.ldw, n_blk, a.N, (k_begin + (s + 1) * KT) * TT<T>::SZ, ws(cur ^ 1));
+            else sw.fetch(a.W, a.ldw, n_blk, a.N, k_begin + (s + 1) * KT, k_end, a.w_op);
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -227,10 +249,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
                 for (int n = 0; n < WM; ++n) mma_chunk<T>(acc[m][n], af[m], bfr[n]);
         }
         if (s + 1 < nsteps) {
-            sx.store(xs(cur ^ 1));
-            sw.store(ws(cur ^ 1));
+            if constexpr (!GX) sx.store(xs(cur ^ 1));
+            if constexpr (!GW) sw.store(ws(cur ^ 1));
         }
-        __syncthreads();
+        __syncthreads();                                 // also drains the in-flight global_load_lds (vmcnt(0))
     }
 
     if constexpr (XT) {
@@ -252,10 +274,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         }
     }
     // ---- epilogue: lane holds C[m][n0..n0+3], m = col of the MFMA tile, n = rows -------------
+    // bf16 outputs are staged through LDS ([m][n] rows, 16-byte slots XOR-swizzled by row) and written back as whole
+    // rows, 16 bytes per lane with consecutive lanes along n -- the direct form is 8 bytes per lane, 16 rows per store.
     const int l = lane_id();
+    constexpr int SROW = BN * 2, SLOTS = SROW / 16, SMASK = SLOTS >= 16 ? 15 : SLOTS - 1;
+    bool staged = false;
+    if constexpr (sizeof(T) == 2) {
+        // measured on MI355X (tools/gemm_bench.py): the staged form is ~20 % SLOWER on every shape of the step -- L2 merges the
+        // 8-byte row pieces fine and the extra barrier + LDS pass costs more than it saves.  Kept for reference, disabled.
+        staged = false && !a.out_f32 && ((uintptr_t)a.C & 15) == 0 && (a.ldc & 7) == 0 &&
+                 (!a.C2 || (((uintptr_t)a.C2 & 15) == 0 && (a.ldc2 & 7) == 0));
+    }
+    char* st1 = smem;                                    // [BM][BN] bf16 for C
+    char* st2 = smem + BM * SROW;                        // [BM][BN] bf16 for C2
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt) {
-        const int m = m_blk + wm0 + mt * 16 + (l & 15);
+        const int ml = wm0 + mt * 16 + (l & 15);
+        const int m = m_blk + ml;
         if (m >= a.M) continue;
         const float rs = a.rowscale ? a.rowscale[m / a.rows_per_scale] : 1.0f;
 #pragma unroll
@@ -290,6 +325,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += rr[r];
             }
+            if (staged) {
+                const int nl = wn0 + nt * 16 + ((l >> 4) << 2);                 // column inside the tile
+                const int off = ml * SROW + ((((nl * 2) >> 4) ^ (ml & SMASK)) << 4) + ((nl * 2) & 8);
+                *reinterpret_cast<uint2*>(st1 + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                if (a.C2) *reinterpret_cast<uint2*>(st2 + off) = make_uint2(pack_bf2(gelu_f(v[0]), gelu_f(v[1])), pack_bf2(gelu_f(v[2]), gelu_f(v[3])));
+                continue;
+            }
             if (a.C2) {
                 T* c2 = reinterpret_cast<T*>(a.C2) + (long)m * a.ldc2 + n0;
                 const float g0 = gelu_f(v[0]), g1 = gelu_f(v[1]), g2 = gelu_f(v[2]), g3 = gelu_f(v[3]);
@@ -314,28 +356,58 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
             }
         }
     }
+    if constexpr (sizeof(T) == 2) {
+        if (staged) {                                    // block-uniform
+            __syncthreads();
+            for (int c = threadIdx.x; c < BM * SLOTS; c += 256) {
+                const int row = c / SLOTS, slot = c % SLOTS;
+                const int m = m_blk + row, n = n_blk + slot * 8;
+                if (m >= a.M || n >= a.N) continue;
+                const int off = row * SROW + ((slot ^ (row & SMASK)) << 4);
+                const uint4 v1 = *reinterpret_cast<const uint4*>(st1 + off);
+                bf16raw* cp = reinterpret_cast<bf16raw*>(a.C) + (long)m * a.ldc + n;
+                if (n + 8 <= a.N) *reinterpret_cast<uint4*>(cp) = v1;
+                else *reinterpret_cast<uint2*>(cp) = make_uint2(v1.x, v1.y);           // N % 8 == 4 tail
+                if (a.C2) {
+                    const uint4 v2 = *reinterpret_cast<const uint4*>(st2 + off);
+                    bf16raw* c2 = reinterpret_cast<bf16raw*>(a.C2) + (long)m * a.ldc2 + n;
+                    if (n + 8 <= a.N) *reinterpret_cast<uint4*>(c2) = v2;
+                    else *reinterpret_cast<uint2*>(c2) = make_uint2(v2.x, v2.y);
+                }
+            }
+        }
+    }
 }
 
-template <typename T, int BN, bool XT, bool WT>
+template <typename T, int BN, bool XT, bool WT, bool GX, bool GW>
 int launch(const GemmArgs& a, hipStream_t st) {
     const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, BN, XT, WT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, BN, XT, WT, GX, GW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid(fw_cdiv(a.M, BM), fw_cdiv(a.N, BN), a.splitk);
-    hipLaunchKernelGGL((gemm_kernel<T, BN, XT, WT>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((gemm_kernel<T, BN, XT, WT, GX, GW>), grid, dim3(256), lds, st, a);
     FW_LAUNCH_RET();
 }
 
 template <typename T, int BN>
 int dispatch_trans(const GemmArgs& a, int xt, int wt, hipStream_t st) {
-    if (!xt && !wt) return launch<T, BN, false, false>(a, st);
-    if (!xt && wt) return launch<T, BN, false, true>(a, st);
-    if (xt && !wt) return launch<T, BN, true, false>(a, st);
-    return launch<T, BN, true, true>(a, st);
+    // direct global->LDS staging for k-contiguous operands whose K range is a whole number of 128-byte steps
+    const int kt = 128 / TT<T>::SZ;
+    const bool whole = a.K % kt == 0;
+    const bool gx = !xt && whole && a.x_op == 0, gw = !wt && whole && a.w_op == 0;
+    if (!xt && !wt) {
+        if (gx && gw) return launch<T, BN, false, false, true, true>(a, st);
+        if (gx) return launch<T, BN, false, false, true, false>(a, st);
+        if (gw) return launch<T, BN, false, false, false, true>(a, st);
+        return launch<T, BN, false, false, false, false>(a, st);
+    }
+    if (!xt && wt) return gx ? launch<T, BN, false, true, true, false>(a, st) : launch<T, BN, false, true, false, false>(a, st);
+    if (xt && !wt) return gw ? launch<T, BN, true, false, false, true>(a, st) : launch<T, BN, true, false, false, false>(a, st);
+    return launch<T, BN, true, true, false, false>(a, st);
 }
 
 }  // namespace

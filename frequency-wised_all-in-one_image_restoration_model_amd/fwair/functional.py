@@ -601,7 +601,6 @@ class LfsLambdaFn(torch.autograd.Function):
                         k += 1
             tabs = (ptab.to(dev), torch.tensor(heads_list, dtype=torch.int32).to(dev),
                     torch.tensor(offs[:-1], dtype=torch.int64).to(dev), offs[-1], gflat, gt.to(dev))
-            _lfs_tables.clear()
             _lfs_tables[key] = tabs
         ptab, heads, coef_off, ncoef, gflat, gt = tabs
         offs = [ncoef]
@@ -622,11 +621,29 @@ class LfsLambdaFn(torch.autograd.Function):
         C = inter.shape[1]
         nblk = len(heads_list)
         gflat, gt = ctx.gbuf
-        gflat.zero_()
-        grads, o = [], 0
-        for p in params:
-            grads.append(gflat[o:o + p.numel()].view_as(p))
-            o += p.numel()
+        direct = config.direct_grads and all(p.grad is not None for p in params)
+        if direct:
+            # engine mode: the kernel's atomics land in the parameters' flat .grad views (704 tiny tensors: no per-tensor add)
+            key = ('direct',) + tuple(p.grad.data_ptr() for p in params)
+            gt2 = _lfs_tables.get(key)
+            if gt2 is None:
+                t = torch.zeros((nblk, 2, 8), dtype=torch.int64)
+                k = 0
+                for bi in range(nblk):
+                    for band in range(nb1):
+                        for j in range(8):
+                            t[bi, band, j] = params[k].grad.data_ptr()
+                            k += 1
+                gt2 = t.to(dev)
+                _lfs_tables[key] = gt2
+            gt = gt2
+            grads = [None] * len(params)
+        else:
+            gflat.zero_()
+            grads, o = [], 0
+            for p in params:
+                grads.append(gflat[o:o + p.numel()].view_as(p))
+                o += p.numel()
         dxbar = torch.zeros_like(xbar)
         call('fw_lfs_lambda_bwd', xbar, ptab, gt, heads, coef_off, dcoef.contiguous(), save, dxbar, nblk, B, C, nb1)
         dinter = torch.zeros_like(inter)

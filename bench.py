@@ -27,6 +27,7 @@ FLOP_PER_IMAGE_STEP = 554.9e9        # 3*(34.72+138.66)+34.72 GF
 PEAK_BF16 = 2.5e15                   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_MFMA = 157.3e12
 PEAK_HBM = 8.0e12
+PEAK_FOR = {'bf16': PEAK_BF16, 'f32': PEAK_F32_MFMA}
 
 
 def synth_batch(B, size, sigma, seed, device):
@@ -61,8 +62,10 @@ def make_opt(batch, dtype):
 
 
 def gemm_profile(engine, batch, steps=2):
-    """HIP-event timing of every fw_gemm launch of `steps` eager training steps, on the stream the kernels run on."""
-    from fwair import lib, ops
+    """HIP-event timing of every fw_gemm launch of `steps` eager training steps, on the stream the kernels run on.
+    Per launch: algorithmic FLOPs 2*M*N*K and algorithmic bytes = every operand / result element touched once
+    (X, W, C, plus the optional f32 residual, aux, second output)."""
+    from fwair import ops
     rec = []
     orig = ops.gemm
 
@@ -71,8 +74,17 @@ def gemm_profile(engine, batch, steps=2):
         a.record()
         r = orig(x, w, M, N, K, **kw)
         b.record()
+        sz = x.element_size()
+        sk = max(1, int(kw.get('splitk', 1) or 1))
+        by = (M * K + N * K) * sz + M * N * r.element_size() * sk
+        if kw.get('accumulate'):
+            by += M * N * r.element_size()
+        for key in ('residual', 'aux', 'out_gelu'):
+            t = kw.get(key)
+            if t is not None:
+                by += M * N * t.element_size()
         variant = ('bf16' if x.dtype == torch.bfloat16 else 'f32', 64 if N <= 64 else 128, bool(kw.get('x_trans')), bool(kw.get('w_trans')))
-        rec.append((variant, 2.0 * M * N * K, a, b))
+        rec.append((variant, (M, N, K, sk), 2.0 * M * N * K, float(by), a, b))
         return r
 
     ops.gemm = timed
@@ -82,10 +94,23 @@ def gemm_profile(engine, batch, steps=2):
         torch.cuda.synchronize()
     finally:
         ops.gemm = orig
-    agg = {}
-    for variant, fl, a, b in rec:
-        d = agg.setdefault(variant, [0.0, 0.0, 0])
-        d[0] += fl; d[1] += a.elapsed_time(b) * 1e-3; d[2] += 1
+    agg, shapes = {}, {}
+    for variant, shape, fl, by, a, b in rec:
+        t = a.elapsed_time(b) * 1e-3
+        d = agg.setdefault(variant, [0.0, 0.0, 0, 0.0, 0.0])
+        d[0] += fl; d[1] += t; d[2] += 1; d[3] += by
+        d[4] += max(fl / PEAK_FOR[variant[0]], by / PEAK_HBM)          # time the launch would take at its roofline
+        e = shapes.setdefault((variant, shape), [0.0, 0.0, 0, 0.0])
+        e[0] += fl; e[1] += t; e[2] += 1; e[3] += by
+    dump = os.environ.get('FW_GEMM_DUMP')
+    if dump:
+        with open(dump, 'w') as f:
+            f.write('dtype,BN,xT,wT,M,N,K,splitk,launches_per_step,us_per_launch,ms_per_step,TFLOPs,GBs,roofline_us\n')
+            for (v, sh), e in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                n = e[2]
+                roof = max(e[0] / n / PEAK_FOR[v[0]], e[3] / n / PEAK_HBM) * 1e6
+                f.write(f'{v[0]},{v[1]},{int(v[2])},{int(v[3])},{sh[0]},{sh[1]},{sh[2]},{sh[3]},{n / steps:g},{e[1] / n * 1e6:.1f},'
+                        f'{e[1] / steps * 1e3:.3f},{e[0] / e[1] / 1e12:.1f},{e[3] / e[1] / 1e9:.0f},{roof:.1f}\n')
     return agg, len(rec) // steps
 
 
@@ -210,13 +235,19 @@ def main():
         agg, launches = gemm_profile(eng, data)
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         tot_t = sum(v[1] for v in agg.values())
-        v, (fl, tt, cnt) = dom
-        res['roofline'] = {'bound': 'mfma', 'kernel': f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>',
-                           'achieved': round(fl / tt / 1e12, 2), 'peak': peak / 1e12, 'unit': 'TFLOP/s',
-                           'frac': round(fl / tt / peak, 5), 'traffic': None, 'avg_launch_us': round(tt / cnt * 1e6, 2),
+        v, (fl, tt, cnt, by, troof) = dom
+        # the variant's launches are priced one by one against max(FLOPs / MFMA peak, bytes / HBM peak); `bound` is the
+        # side that sets most of that time, `achieved` / `peak` are quoted in its unit, `frac` = roofline time / measured
+        hbm = by / PEAK_HBM > fl / peak
+        res['roofline'] = {'bound': 'hbm' if hbm else 'mfma', 'kernel': f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>',
+                           'achieved': round((by / tt / 1e9) if hbm else (fl / tt / 1e12), 2),
+                           'peak': (PEAK_HBM / 1e9) if hbm else (peak / 1e12), 'unit': 'GB/s' if hbm else 'TFLOP/s',
+                           'frac': round(troof / tt, 5), 'traffic': None, 'avg_launch_us': round(tt / cnt * 1e6, 2),
+                           'tflops': round(fl / tt / 1e12, 2), 'algorithmic_gbs': round(by / tt / 1e9, 1),
                            'launches_per_step': cnt // 2, 'gemm_launches_per_step': launches,
                            'gemm_time_ms_per_step': round(tot_t / 2 * 1e3, 3),
-                           'all_gemm_tflops': round(sum(x[0] for x in agg.values()) / tot_t / 1e12, 2)}
+                           'all_gemm_tflops': round(sum(x[0] for x in agg.values()) / tot_t / 1e12, 2),
+                           'all_gemm_roofline_frac': round(sum(x[4] for x in agg.values()) / tot_t, 5)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(host_threads())
     if rank == 0:

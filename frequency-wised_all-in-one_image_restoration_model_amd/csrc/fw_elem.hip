@@ -150,9 +150,9 @@ __global__ void dwconv_strip_kernel(const T* __restrict__ in, long ldi, const fl
 
 // weight / bias gradient.  block = 32 strip-groups x 8 channel vectors; a thread walks NSTRIP consecutive strips with its
 // 10 x E partial sums in registers; partials are reduced over the block (shuffles + LDS) before ONE atomic per word.
-template <typename T, int NSTRIP>
+template <typename T>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dh2, long ldg, const T* __restrict__ g1, long ld1,
-                                                           float* __restrict__ dw, float* __restrict__ dbias, int B, int H, int W, int C) {
+                                                           float* __restrict__ dw, float* __restrict__ dbias, int B, int H, int W, int C, int NSTRIP) {
     constexpr int E = TT<T>::E16;
     __shared__ float red[8 * E * 10];
     const int nv = C / E, ns = W / SX;
@@ -641,19 +641,20 @@ extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g
     const int e = dtype == FW_DT_BF16 ? 8 : 4;
     FW_CHECK_ARG(dh2 && g1 && h1 && w && dh1 && dw && dbias && C % e == 0 && ld1 % e == 0 && ldg % e == 0 && ldo % e == 0 && W % SX == 0);
     FW_CHECK_ARG(ldg == ld1);                      // the data-gradient strip kernel walks dh2 and h1 with one row stride
-    constexpr int NSTRIP = 8;
     const long n = (long)B * H * (W / SX) * (C / e);
     const int nvg = (C / e + 7) / 8;
+    int NSTRIP = 8;                                // strips per thread: fewer on small layers so that >= ~1000 blocks are in flight
+    while (NSTRIP > 1 && ((((long)B * H * (W / SX) + NSTRIP - 1) / NSTRIP + 31) / 32) * nvg < 1024) NSTRIP >>= 1;
     const long nsg = (((long)B * H * (W / SX) + NSTRIP - 1) / NSTRIP + 31) / 32;
     const dim3 gridw((unsigned)(nsg * nvg));
     if (dtype == FW_DT_BF16) {
         hipLaunchKernelGGL((dwconv_strip_kernel<bf16raw, 1>), dim3(grid_for(n)), dim3(TPB), 0, ST, (const bf16raw*)dh2, ldg, w, (const float*)nullptr,
                            (const bf16raw*)h1, (bf16raw*)dh1, (bf16raw*)nullptr, ldo, B, H, W, C);
-        hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16raw, NSTRIP>), gridw, dim3(256), 0, ST, (const bf16raw*)dh2, ldg, (const bf16raw*)g1, ld1, dw, dbias, B, H, W, C);
+        hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16raw>), gridw, dim3(256), 0, ST, (const bf16raw*)dh2, ldg, (const bf16raw*)g1, ld1, dw, dbias, B, H, W, C, NSTRIP);
     } else {
         hipLaunchKernelGGL((dwconv_strip_kernel<float, 1>), dim3(grid_for(n)), dim3(TPB), 0, ST, (const float*)dh2, ldg, w, (const float*)nullptr,
                            (const float*)h1, (float*)dh1, (float*)nullptr, ldo, B, H, W, C);
-        hipLaunchKernelGGL((dwconv_wgrad_kernel<float, NSTRIP>), gridw, dim3(256), 0, ST, (const float*)dh2, ldg, (const float*)g1, ld1, dw, dbias, B, H, W, C);
+        hipLaunchKernelGGL((dwconv_wgrad_kernel<float>), gridw, dim3(256), 0, ST, (const float*)dh2, ldg, (const float*)g1, ld1, dw, dbias, B, H, W, C, NSTRIP);
     }
     FW_LAUNCH_RET();
 }

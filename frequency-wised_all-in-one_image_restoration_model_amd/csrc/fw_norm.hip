@@ -80,8 +80,8 @@ template <typename T, int G>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres, long lddres,
-                                                     float* __restrict__ dx, long lddx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows, int C) {
+                                                     float* __restrict__ dx, long lddx, float* __restrict__ partial,
+                                                     long pstride, int rows, int C) {
     constexpr int RPB = 256 / G;
     const int gl = threadIdx.x % G, gr = threadIdx.x / G;
     const int nv = C >> 2;
@@ -155,9 +155,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, l
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        atomicAdd(dgamma + c, red[0][c]);
-        atomicAdd(dbeta + c, red[1][c]);
+    // block partials [block][dgamma(Cp) | dbeta(Cp)]: plain stores; fw_slab_reduce folds them (thousands of blocks adding
+    // atomically into the same C words serialise in L2 and cost more than the whole LayerNorm pass)
+    float* pp = partial + (long)blockIdx.x * pstride;
+    const int Cp = (int)(pstride >> 1);
+    for (int c = threadIdx.x; c < Cp; c += 256) {
+        pp[c] = c < C ? red[0][c] : 0.f;
+        pp[Cp + c] = c < C ? red[1][c] : 0.f;
     }
 }
 
@@ -169,14 +173,15 @@ int ln_fwd_launch(const float* x, long ldx, const float* g, const float* b, void
                        mean, rstd, rows, C, eps);
     FW_LAUNCH_RET();
 }
+static inline int ln_group(int C) { return C <= 64 ? 16 : (C <= 128 ? 32 : 64); }
+static inline int ln_bwd_grid(int rows, int C) { return min(fw_cdiv(rows, 256 / ln_group(C)), 2048); }
+
 template <typename T, int G>
 int ln_bwd_launch(const void* dy, long lddy, const float* x, long ldx, const float* g, const float* mean,
-                  const float* rstd, const float* dres, long lddres, float* dx, long lddx, float* dgamma, float* dbeta,
+                  const float* rstd, const float* dres, long lddres, float* dx, long lddx, float* partial, long pstride,
                   int rows, int C, hipStream_t st) {
-    const int rpb = 256 / G;
-    const int grid = min(fw_cdiv(rows, rpb), 2048);
-    hipLaunchKernelGGL((ln_bwd_kernel<T, G>), dim3(grid), dim3(256), 0, st, (const T*)dy, lddy, x, ldx, g, mean, rstd,
-                       dres, lddres, dx, lddx, dgamma, dbeta, rows, C);
+    hipLaunchKernelGGL((ln_bwd_kernel<T, G>), dim3(ln_bwd_grid(rows, C)), dim3(256), 0, st, (const T*)dy, lddy, x, ldx, g, mean, rstd,
+                       dres, lddres, dx, lddx, partial, pstride, rows, C);
     FW_LAUNCH_RET();
 }
 
@@ -195,19 +200,29 @@ extern "C" int fw_layernorm_fwd(int dtype, const float* x, long ldx, const float
 #undef LN_F
 }
 
+// Number of block partials fw_layernorm_bwd writes for (rows, C): the caller provides `partial` f32 [blocks][2 * roundup(C, 4)].
+extern "C" int fw_layernorm_bwd_blocks(int rows, int C) { return ln_bwd_grid(rows, C); }
+
+// dx = (dres?) + LN'(dy).  The per-block column sums of dy*xhat / dy go to `partial` (plain stores) and are folded into
+// dgamma / dbeta (accumulated) by fw_slab_reduce, launched here on the same stream.
+extern "C" int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, float* dst2, long off2, long n2,
+                              void* stream);
 extern "C" int fw_layernorm_bwd(int dtype, const void* dy, long lddy, const float* x, long ldx, const float* gamma,
                                 const float* mean, const float* rstd, const float* dres, long lddres, float* dx,
-                                long lddx, float* dgamma, float* dbeta, int rows, int C, void* stream) {
+                                long lddx, float* dgamma, float* dbeta, float* partial, int rows, int C, void* stream) {
     FW_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0);
-    FW_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta);
+    FW_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partial);
     hipStream_t st = (hipStream_t)stream;
+    const long pstride = 2L * C;
 #define LN_B(T)                                                                                                      \
-    (C <= 64 ? ln_bwd_launch<T, 16>(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, dgamma, dbeta, rows, \
+    (C <= 64 ? ln_bwd_launch<T, 16>(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, partial, pstride, rows, \
                                     C, st)                                                                           \
-             : C <= 128 ? ln_bwd_launch<T, 32>(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, dgamma,  \
-                                               dbeta, rows, C, st)                                                   \
-                        : ln_bwd_launch<T, 64>(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, dgamma,  \
-                                               dbeta, rows, C, st))
-    return dtype == FW_DT_BF16 ? LN_B(bf16raw) : LN_B(float);
+             : C <= 128 ? ln_bwd_launch<T, 32>(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, partial,  \
+                                               pstride, rows, C, st)                                                 \
+                        : ln_bwd_launch<T, 64>(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, partial,  \
+                                               pstride, rows, C, st))
+    const int rc = dtype == FW_DT_BF16 ? LN_B(bf16raw) : LN_B(float);
 #undef LN_B
+    if (rc) return rc;
+    return fw_slab_reduce(partial, ln_bwd_grid(rows, C), C, pstride, dgamma, 1, dbeta, C, C, stream);
 }

@@ -4,7 +4,7 @@ libfwair_hip.so.  Activations are 2-D [tokens, channels] tensors whose row strid
 import torch
 
 from . import lfs as _lfs
-from .lib import call, dt
+from .lib import call, dt, lib
 
 
 def _ld(t):
@@ -71,8 +71,10 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
     rows, C = x.shape
     dx = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    nblk = lib().fw_layernorm_bwd_blocks(rows, C)
+    partial = torch.empty((nblk, 2 * C), dtype=torch.float32, device=x.device)
     call('fw_layernorm_bwd', dt(dy.dtype), dy, _ld(dy), x, _ld(x), gamma, mean, rstd, dres,
-         _ld(dres) if dres is not None else 0, dx, _ld(dx), dgamma, dbeta, rows, C)
+         _ld(dres) if dres is not None else 0, dx, _ld(dx), dgamma, dbeta, partial, rows, C)
     return dx
 
 

@@ -42,10 +42,12 @@ int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, 
 /* ---- LayerNorm over the f32 stream -> T (decoder_Uformer.py:567,594,666,744; encoder_Uformer.py:941) -- */
 int fw_layernorm_fwd(int dtype, const float* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
                      float* mean, float* rstd, int rows, int C, float eps, void* stream);
-/* dx = (dres?) + LN'(dy); dgamma, dbeta accumulated */
+/* dx = (dres?) + LN'(dy); dgamma, dbeta accumulated.  partial: caller scratch f32 [fw_layernorm_bwd_blocks(rows, C)][2*C]
+ * for the per-block column sums (folded with fw_slab_reduce instead of thousands of same-address atomics). */
+int fw_layernorm_bwd_blocks(int rows, int C);
 int fw_layernorm_bwd(int dtype, const void* dy, long lddy, const float* x, long ldx, const float* gamma, const float* mean,
                      const float* rstd, const float* dres, long lddres, float* dx, long lddx, float* dgamma, float* dbeta,
-                     int rows, int C, void* stream);
+                     float* partial, int rows, int C, void* stream);
 
 /* ---- window attention (decoder_Uformer.py:240-293 with :387-409,634-651,678-686,721-729 folded in;
  *      encoder_Uformer.py:152-183 "origin", :256-310 intra / inter band attention) ---------------------

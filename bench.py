@@ -83,7 +83,10 @@ def gemm_profile(engine, batch, steps=2):
             t = kw.get(key)
             if t is not None:
                 by += M * N * t.element_size()
-        variant = ('bf16' if x.dtype == torch.bfloat16 else 'f32', 64 if N <= 64 else 128, bool(kw.get('x_trans')), bool(kw.get('w_trans')))
+        stream = (not kw.get('x_trans') and sk == 1 and not kw.get('accumulate') and not kw.get('x_op') and not kw.get('w_op')
+                  and kw.get('xsum') is None and K * sz <= 512 and M >= 32768)          # fw_gemm's dispatch rule
+        variant = ('bf16' if x.dtype == torch.bfloat16 else 'f32', 'stream' if stream else (64 if N <= 64 else 128),
+                   bool(kw.get('x_trans')), bool(kw.get('w_trans')))
         rec.append((variant, (M, N, K, sk), 2.0 * M * N * K, float(by), a, b))
         return r
 
@@ -239,7 +242,7 @@ def main():
         # the variant's launches are priced one by one against max(FLOPs / MFMA peak, bytes / HBM peak); `bound` is the
         # side that sets most of that time, `achieved` / `peak` are quoted in its unit, `frac` = roofline time / measured
         hbm = by / PEAK_HBM > fl / peak
-        res['roofline'] = {'bound': 'hbm' if hbm else 'mfma', 'kernel': f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>',
+        res['roofline'] = {'bound': 'hbm' if hbm else 'mfma', 'kernel': (f'gemm_stream_kernel<{v[0]},wT={int(v[3])}>' if v[1] == 'stream' else f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>'),
                            'achieved': round((by / tt / 1e9) if hbm else (fl / tt / 1e12), 2),
                            'peak': (PEAK_HBM / 1e9) if hbm else (peak / 1e12), 'unit': 'GB/s' if hbm else 'TFLOP/s',
                            'frac': round(troof / tt, 5), 'traffic': None, 'avg_launch_us': round(tt / cnt * 1e6, 2),

@@ -9,11 +9,15 @@
 // [225, heads] table (:245-251), and the SW-MSA mask (:634-651) rebuilt from the window coordinates
 // (-100 where the two tokens lie in different shift regions, exactly as the reference adds it).
 //
-// MI355X design.  One 64-lane wave owns one (window, head) item end to end; the 64x64 score tile never
-// leaves the CU.  Every contraction is an MFMA "NT" product of two k-contiguous LDS tiles
-// (fw_common.h), and every product is oriented so that its result -- which the C/D layout delivers
-// with 4 consecutive ROWS per lane -- is written back to LDS TRANSPOSED with one 8/16-byte store and
-// is then exactly the k-contiguous operand the next product needs:
+// MI355X design.  One workgroup of 4 waves owns one (window, head) item end to end; the 64x64 score tile
+// never leaves the CU.  Wave w owns the 16-column strip w of every 64-wide product (queries 16w..16w+15 of
+// S^T / P / dP / dS, keys 16w..16w+15 of dV / dK), so softmax, D_i and the bias-gradient accumulators are
+// wave-local and the register tile is 4 MFMA tiles instead of 16; the A-operands (K, V, dO, Q, DFT panels) are
+// shared through LDS.  2 workgroups fit a CU (bf16): 8 waves hide each other's LDS / L2 latency.
+// Every contraction is an MFMA "NT" product of two k-contiguous LDS tiles (fw_common.h), and every product is
+// oriented so that its result -- which the C/D layout delivers with 4 consecutive ROWS per lane -- is written
+// back to LDS TRANSPOSED with one 8/16-byte store and is then exactly the k-contiguous operand the next product
+// needs; operands needed along the other axis are read with the transposing LDS read (ds_read_b64_tr_b16):
 //     S^T[j][i] = K Q^T        softmax over j = registers + 2 shuffles (columns i live on lanes)
 //     O^T[d][i] = V^T P'       V read k-major from its row tile; O^T stored transposed -> [i][d]
 // Learned frequency selection: the reference FFTs each 64x64 attention map, masks three radial bands
@@ -92,12 +96,24 @@ FW_DEV long token_row(int n, int wy, int wx, int t, int H, int W, int shift) {
     return ((long)n * H + y) * W + x;
 }
 
-// Copy the 64 window rows of one head ([64][D]) global -> LDS tile (zero padded to whole chunks).
+constexpr int NWV = 4;                       // waves per workgroup = 16-wide strips of the 64x64 tile
+constexpr int NTH = NWV * 64;
+
+FW_DEV int wave_id() { return threadIdx.x >> 6; }
+
+// LDS traffic that stays inside one wave (a strip written and re-read by its owner) needs no block barrier: LDS
+// instructions of a wave execute in order, the fence keeps the compiler from moving accesses across and drains the queue.
+FW_DEV void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Copy the 64 window rows of one head ([64][D]) global -> LDS tile (zero padded to whole chunks); whole workgroup.
 template <typename T, int D>
 FW_DEV void load_tile(char* tile, const char* base, long ld, int n, int wy, int wx, int H, int W, int shift, int col) {
     using G = Geo<T, D>;
-    const int l = lane_id();
-    for (int idx = l; idx < 64 * G::SL; idx += 64) {
+    for (int idx = threadIdx.x; idx < 64 * G::SL; idx += NTH) {
         const int t = idx / G::SL, s = idx % G::SL;
         if (G::CB == 16) {
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -110,13 +126,13 @@ FW_DEV void load_tile(char* tile, const char* base, long ld, int n, int wy, int 
         }
     }
 }
-// Copy a [64][D] LDS tile -> the 64 window rows of one head.
+// Copy rows r0..r0+15 of a [64][D] LDS tile -> the matching window rows of one head; ONE wave (its own strip).
 template <typename T, int D>
-FW_DEV void store_tile(const char* tile, char* base, long ld, int n, int wy, int wx, int H, int W, int shift, int col) {
+FW_DEV void store_rows16(const char* tile, char* base, long ld, int n, int wy, int wx, int H, int W, int shift, int col, int r0) {
     using G = Geo<T, D>;
     const int l = lane_id();
-    for (int idx = l; idx < 64 * G::CH; idx += 64) {
-        const int t = idx / G::CH, s = idx % G::CH;
+    for (int idx = l; idx < 16 * G::CH; idx += 64) {
+        const int t = r0 + idx / G::CH, s = idx % G::CH;
         char* dst = base + (token_row(n, wy, wx, t, H, W, shift) * ld + col) * G::SZ;
         if (G::CB == 16) *reinterpret_cast<uint4*>(dst + s * 16) = *reinterpret_cast<const uint4*>(tile + t * G::LDR + s * 16);
         else *reinterpret_cast<uint2*>(dst + s * 8) = *reinterpret_cast<const uint2*>(tile + t * G::LDR + s * 8);
@@ -136,139 +152,119 @@ FW_DEV float bias_mask(const float* tab, int heads, int h, int i, int j, int shi
     return b;
 }
 
-// sum / max over the rows (j) of a [16*JT][64] score block held as acc[jt][it]: registers + 2 shuffles
+// sum / max over the rows (j) of a [16*JT][16] score strip held as acc[jt]: registers + 2 shuffles
 FW_DEV float col_reduce_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
 FW_DEV float col_reduce_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
 
-// ---- B1: the disc band filter on a 64x64 tile held transposed in registers (in[jt][it] = A^T[j][i]) ----
-// scrA / scrB: two LDS scratch regions of >= 64*LDP and >= 2*64*LDV bytes.  out[jt][it] = B1(A)^T[j][i].
+// ---- B1: the disc band filter on a 64x64 tile held transposed in registers ----------------------------------
+// Wave w passes / receives its strip: in[jt] = A^T[j = 16 jt ..][i = 16 w ..], out[jt] = B1(A)^T likewise.
+// scrA / scrB: two workgroup-wide LDS scratch regions of >= 64*LDP and >= 2*64*LDV bytes that no wave is still reading
+// on entry (the caller has passed a block barrier since their last use); on return both are free again.
 template <typename T>
-FW_DEV void band_filter(const f32x4 (&in)[4][4], f32x4 (&out)[4][4], char* scrA, char* scrB, const char* lfs) {
+FW_DEV void band_filter(const f32x4 (&in)[4], f32x4 (&out)[4], char* scrA, char* scrB, const char* lfs) {
     using G = Geo<T, 56>;
     constexpr int SZ = G::SZ, LDP = G::LDP, LDV = G::LDV, JC = G::JC, VC = G::VC;
     const char* tab = lfs;
     const float* Mw = reinterpret_cast<const float*>(lfs + (size_t)OFF_END * SZ);
-    const int l = lane_id();
-    // Ps[i][j] <- in^T   (scrA)
+    const int l = lane_id(), w = wave_id();
+    // Ps[i][j] <- in^T   (scrA, rows i of the own strip)
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) store_acc_T<T>(scrA, LDP, jt * 16, it * 16, in[jt][it]);
-    __syncthreads();
-    // T[i][v] = sum_j P[i][j] Fv[j][v]   (Tr with cos, Ti with -sin); store transposed -> Ts[v][i] (scrB)
+    for (int jt = 0; jt < 4; ++jt) store_acc_T<T>(scrA, LDP, jt * 16, w * 16, in[jt]);
+    wave_fence();
+    // T[i][v] = sum_j P[i][j] Fv[j][v]   (Tr with cos, Ti with -sin), rows i of the own strip; stored transposed -> Ts[v][i] (scrB)
     {
-        f32x4 tr[4][2], ti[4][2];
-        zero_acc(tr); zero_acc(ti);
-#pragma unroll 1
-        for (int c = 0; c < JC; ++c) {
-            uint4 a[4];
+        f32x4 tr[2], ti[2];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = frag_kc(scrA, LDP, m * 16, c);
+        for (int n = 0; n < 2; ++n) { tr[n] = f32x4{0.f, 0.f, 0.f, 0.f}; ti[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < JC; ++c) {
+            const uint4 a = frag_kc(scrA, LDP, w * 16, c);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const uint4 bc = frag_kc(tab + (size_t)OFF_C2 * SZ, 64 * SZ, n * 16, c);
                 const uint4 bs = frag_kc(tab + (size_t)OFF_S2N * SZ, 64 * SZ, n * 16, c);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) { mma_chunk<T>(tr[m][n], a[m], bc); mma_chunk<T>(ti[m][n], a[m], bs); }
+                mma_chunk<T>(tr[n], a, bc); mma_chunk<T>(ti[n], a, bs);
             }
         }
-        __syncthreads();
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int n = 0; n < 2; ++n) {
+            store_acc_T<T>(scrB, LDP, w * 16, n * 16, tr[n]);                 // Tr^T [v][i]
+            store_acc_T<T>(scrB + 32 * LDP, LDP, w * 16, n * 16, ti[n]);      // Ti^T [v][i]
+        }
+    }
+    __syncthreads();                         // T complete (all strips); every wave is done reading Ps
+    // X[u][v] = sum_i Fu[u][i] T[i][v]:  Xr = Cu Tr + Su Ti,  Xi = Cu Ti - Su Tr;  Y = Mw * X -> Ys[v][u] (scrA)
+    // 3 row tiles of u (|fu| <= 22 -> 48 rows): waves 0..2 take one each, wave 3 clears the k padding u = 48..63 of Ys
+    if (w < 3) {
+        f32x4 xr[2], xi[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { xr[n] = f32x4{0.f, 0.f, 0.f, 0.f}; xi[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < JC; ++c) {
+            const uint4 ac = frag_kc(tab + (size_t)OFF_CU * SZ, 64 * SZ, w * 16, c);
+            const uint4 as = frag_kc(tab + (size_t)OFF_SU * SZ, 64 * SZ, w * 16, c);
+            const uint4 an = frag_kc(tab + (size_t)OFF_SUN * SZ, 64 * SZ, w * 16, c);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                store_acc_T<T>(scrB, LDP, m * 16, n * 16, tr[m][n]);                 // Tr^T [v][i]
-                store_acc_T<T>(scrB + 32 * LDP, LDP, m * 16, n * 16, ti[m][n]);      // Ti^T [v][i]
-            }
-    }
-    __syncthreads();
-    // X[u][v] = sum_i Fu[u][i] T[i][v]:  Xr = Cu Tr + Su Ti,  Xi = Cu Ti - Su Tr;  Y = Mw * X -> Ys[v][u] (scrA)
-    {
-        f32x4 xr[3][2], xi[3][2];
-        zero_acc(xr); zero_acc(xi);
-#pragma unroll 1
-        for (int c = 0; c < JC; ++c) {
-            uint4 br[2], bi[2];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) { br[n] = frag_kc(scrB, LDP, n * 16, c); bi[n] = frag_kc(scrB + 32 * LDP, LDP, n * 16, c); }
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const uint4 ac = frag_kc(tab + (size_t)OFF_CU * SZ, 64 * SZ, m * 16, c);
-                const uint4 as = frag_kc(tab + (size_t)OFF_SU * SZ, 64 * SZ, m * 16, c);
-                const uint4 an = frag_kc(tab + (size_t)OFF_SUN * SZ, 64 * SZ, m * 16, c);
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    mma_chunk<T>(xr[m][n], ac, br[n]); mma_chunk<T>(xr[m][n], as, bi[n]);
-                    mma_chunk<T>(xi[m][n], ac, bi[n]); mma_chunk<T>(xi[m][n], an, br[n]);
-                }
+                const uint4 br = frag_kc(scrB, LDP, n * 16, c), bi = frag_kc(scrB + 32 * LDP, LDP, n * 16, c);
+                mma_chunk<T>(xr[n], ac, br); mma_chunk<T>(xr[n], as, bi);
+                mma_chunk<T>(xi[n], ac, bi); mma_chunk<T>(xi[n], an, br);
             }
         }
-        __syncthreads();
-        // zero the k padding u = 48..63 of Ys (two [32][64] panels)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f32x4 wt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wt[r] = Mw[(w * 16 + ((l >> 4) << 2) + r) * NV + n * 16 + (l & 15)];
+            store_acc_T<T>(scrA, LDP, w * 16, n * 16, xr[n] * wt);             // Yr^T [v][u]
+            store_acc_T<T>(scrA + 32 * LDP, LDP, w * 16, n * 16, xi[n] * wt);  // Yi^T [v][u]
+        }
+    } else {
         for (int idx = l; idx < 64 * 4; idx += 64) {
             const int row = idx >> 2, part = idx & 3;          // 64 rows (2 panels x 32), 16 pad elements in 4 parts
             char* p = scrA + row * LDP + 48 * SZ + part * 4 * SZ;
             if (SZ == 4) *reinterpret_cast<uint4*>(p) = make_uint4(0, 0, 0, 0); else *reinterpret_cast<uint2*>(p) = make_uint2(0, 0);
         }
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                f32x4 w;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = Mw[(m * 16 + ((l >> 4) << 2) + r) * NV + n * 16 + (l & 15)];
-                store_acc_T<T>(scrA, LDP, m * 16, n * 16, xr[m][n] * w);             // Yr^T [v][u]
-                store_acc_T<T>(scrA + 32 * LDP, LDP, m * 16, n * 16, xi[m][n] * w);  // Yi^T [v][u]
-            }
     }
-    __syncthreads();
-    // Z^T[v][i] = sum_u Y^T[v][u] FuH[i][u]:  Zr = Yr C - Yi S,  Zi = Yi C + Yr S;  store transposed -> Zs[i][v] (scrB)
+    __syncthreads();                         // Y complete; every wave is done reading T
+    // Z^T[v][i] = sum_u Y^T[v][u] FuH[i][u]:  Zr = Yr C - Yi S,  Zi = Yi C + Yr S;  own columns i; stored transposed -> Zs[i][v] (scrB)
     {
-        f32x4 zr[2][4], zi[2][4];
-        zero_acc(zr); zero_acc(zi);
-#pragma unroll 1
+        f32x4 zr[2], zi[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { zr[m] = f32x4{0.f, 0.f, 0.f, 0.f}; zi[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
         for (int c = 0; c < JC; ++c) {
-            uint4 ar[2], ai[2];
+            const uint4 bc = frag_kc(tab + (size_t)OFF_CH * SZ, 64 * SZ, w * 16, c);
+            const uint4 bs = frag_kc(tab + (size_t)OFF_SH * SZ, 64 * SZ, w * 16, c);
+            const uint4 bn = frag_kc(tab + (size_t)OFF_SHN * SZ, 64 * SZ, w * 16, c);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) { ar[m] = frag_kc(scrA, LDP, m * 16, c); ai[m] = frag_kc(scrA + 32 * LDP, LDP, m * 16, c); }
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const uint4 bc = frag_kc(tab + (size_t)OFF_CH * SZ, 64 * SZ, n * 16, c);
-                const uint4 bs = frag_kc(tab + (size_t)OFF_SH * SZ, 64 * SZ, n * 16, c);
-                const uint4 bn = frag_kc(tab + (size_t)OFF_SHN * SZ, 64 * SZ, n * 16, c);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    mma_chunk<T>(zr[m][n], ar[m], bc); mma_chunk<T>(zr[m][n], ai[m], bn);
-                    mma_chunk<T>(zi[m][n], ai[m], bc); mma_chunk<T>(zi[m][n], ar[m], bs);
-                }
+            for (int m = 0; m < 2; ++m) {
+                const uint4 ar = frag_kc(scrA, LDP, m * 16, c), ai = frag_kc(scrA + 32 * LDP, LDP, m * 16, c);
+                mma_chunk<T>(zr[m], ar, bc); mma_chunk<T>(zr[m], ai, bn);
+                mma_chunk<T>(zi[m], ai, bc); mma_chunk<T>(zi[m], ar, bs);
             }
         }
-        __syncthreads();
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                store_acc_T<T>(scrB, LDV, m * 16, n * 16, zr[m][n]);                 // Zr [i][v]
-                store_acc_T<T>(scrB + 64 * LDV, LDV, m * 16, n * 16, zi[m][n]);      // Zi [i][v]
-            }
+        for (int m = 0; m < 2; ++m) {
+            store_acc_T<T>(scrB, LDV, m * 16, w * 16, zr[m]);                 // Zr [i][v]
+            store_acc_T<T>(scrB + 64 * LDV, LDV, m * 16, w * 16, zi[m]);      // Zi [i][v]
+        }
     }
-    __syncthreads();
-    // out^T[j][i] = sum_v Gc[j][v] Zr[i][v] + Gsn[j][v] Zi[i][v]
-    zero_acc(out);
-#pragma unroll 1
-    for (int c = 0; c < VC; ++c) {
-        uint4 br[4], bi[4];
+    wave_fence();
+    // out^T[j][i] = sum_v Gc[j][v] Zr[i][v] + Gsn[j][v] Zi[i][v]   (own columns i)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) { br[n] = frag_kc(scrB, LDV, n * 16, c); bi[n] = frag_kc(scrB + 64 * LDV, LDV, n * 16, c); }
+    for (int m = 0; m < 4; ++m) out[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < VC; ++c) {
+        const uint4 br = frag_kc(scrB, LDV, w * 16, c), bi = frag_kc(scrB + 64 * LDV, LDV, w * 16, c);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const uint4 ac = frag_kc(tab + (size_t)OFF_GC * SZ, 32 * SZ, m * 16, c);
             const uint4 as = frag_kc(tab + (size_t)OFF_GSN * SZ, 32 * SZ, m * 16, c);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) { mma_chunk<T>(out[m][n], ac, br[n]); mma_chunk<T>(out[m][n], as, bi[n]); }
+            mma_chunk<T>(out[m], ac, br); mma_chunk<T>(out[m], as, bi);
         }
     }
-    __syncthreads();
+    __syncthreads();                         // both scratch regions are free again
 }
 
 template <typename T, int D, int NKT, int LFS> struct Smem {
@@ -284,22 +280,22 @@ template <typename T, int D, int NKT, int LFS> struct Smem {
 // forward
 // =====================================================================================================
 template <typename T, int D, int NKT, int LFS>
-__global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(NTH, 3) void attn_fwd_kernel(AttnArgs a) {
     using G = Geo<T, D>;
     using S = Smem<T, D, NKT, LFS>;
-    constexpr int SZ = G::SZ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* rA = smem;                        // Q -> P' (and LFS scratch A)
     char* rB = smem + S::RA;                // K tiles (kt) -> LFS scratch B -> O staging
     char* rV = rB + S::RB * NKT;            // V tiles
-    const int l = lane_id();
+    const int l = lane_id(), w = wave_id();
     const int nWx = a.W / 8, nWy = a.H / 8, nW = nWx * nWy;
     const int items = a.nwin * a.L * a.heads;
+    const int i = w * 16 + (l & 15);        // the query this lane's score columns belong to
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
         const int h = item % a.heads;
         const int lq = (item / a.heads) % a.L;
         const int win = item / (a.heads * a.L);
-        const int b = win / nW, w = win % nW, wy = w / nWx, wx = w % nWx;
+        const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
         const bool last_y = wy == nWy - 1, last_x = wx == nWx - 1;
         const int nq = lq * a.B + b;
         load_tile<T, D>(rA, a.q, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
@@ -310,26 +306,20 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
             load_tile<T, D>(rV + kt * G::TILE_D, a.v, a.ld, lk * a.B + b, wy, wx, a.H, a.W, a.shift, h * D);
         }
         __syncthreads();
-        // S^T[j][i] = sum_d K[j][d] Q[i][d]
-        f32x4 p[4 * NKT][4];
-        zero_acc(p);
+        // S^T[j][i] = sum_d K[j][d] Q[i][d], own columns i
+        f32x4 p[4 * NKT];
+#pragma unroll
+        for (int jt = 0; jt < 4 * NKT; ++jt) p[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
             for (int c = 0; c < G::KC; ++c) {
-                uint4 ak[4], bq[4];
+                const uint4 bq = frag_kc(rA, G::LDR, w * 16, c);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) ak[m] = frag_kc(rB + kt * S::RB, G::LDR, m * 16, c);
-#pragma unroll
-                for (int n = 0; n < 4; ++n) bq[n] = frag_kc(rA, G::LDR, n * 16, c);
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) mma_chunk<T>(p[4 * kt + m][n], ak[m], bq[n]);
+                for (int m = 0; m < 4; ++m) mma_chunk<T>(p[4 * kt + m], frag_kc(rB + kt * S::RB, G::LDR, m * 16, c), bq);
             }
         // scale, bias, mask, softmax over j
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int i = it * 16 + (l & 15);
+        {
             float mx = -3.0e38f;
 #pragma unroll
             for (int jt = 0; jt < 4 * NKT; ++jt) {
@@ -339,8 +329,8 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = (jt & 3) * 16 + ((l >> 4) << 2) + r;
-                    const float s = p[jt][it][r] * a.scale + bias_mask(tab, a.heads, h, i, j, a.shift, last_y, last_x);
-                    p[jt][it][r] = s;
+                    const float s = p[jt][r] * a.scale + bias_mask(tab, a.heads, h, i, j, a.shift, last_y, last_x);
+                    p[jt][r] = s;
                     mx = fmaxf(mx, s);
                 }
             }
@@ -349,11 +339,11 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int jt = 0; jt < 4 * NKT; ++jt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = __expf(p[jt][it][r] - mx); p[jt][it][r] = e; sum += e; }
+                for (int r = 0; r < 4; ++r) { const float e = __expf(p[jt][r] - mx); p[jt][r] = e; sum += e; }
             sum = col_reduce_sum(sum);
             const float inv = 1.0f / sum;
 #pragma unroll
-            for (int jt = 0; jt < 4 * NKT; ++jt) p[jt][it] *= inv;
+            for (int jt = 0; jt < 4 * NKT; ++jt) p[jt] *= inv;
             if ((l >> 4) == 0) a.lse[(size_t)item * 64 + i] = mx + __logf(sum);
         }
         __syncthreads();                    // Q / K tiles are dead from here on
@@ -362,48 +352,35 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
             const float* cf = a.coef + ((size_t)b * a.heads + h) * 3;
             const float ca = cf[0], cb = cf[1], cc = cf[2];
             if constexpr (LFS == 2) {
-                f32x4 f1[4][4];
+                f32x4 f1[4];
                 band_filter<T>(p, f1, rA, rB, a.lfs);
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) p[jt][it] = p[jt][it] * ca + cb + f1[jt][it] * cc;
+                for (int jt = 0; jt < 4; ++jt) p[jt] = p[jt] * ca + cb + f1[jt] * cc;
             } else {
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) p[jt][it] = p[jt][it] * ca + cb;
+                for (int jt = 0; jt < 4; ++jt) p[jt] = p[jt] * ca + cb;
             }
         }
-        // P'[i][j] -> rA (transposed store), then O^T[d][i] = sum_j V[j][d] P'[i][j]
+        // P'[i][j] -> rA rows i of the own strip (transposed store), then O^T[d][i] = sum_j V[j][d] P'[i][j]
 #pragma unroll
-        for (int jt = 0; jt < 4 * NKT; ++jt)
+        for (int jt = 0; jt < 4 * NKT; ++jt) store_acc_T<T>(rA, S::LDPK, jt * 16, w * 16, p[jt]);
+        wave_fence();
+        f32x4 o[G::DT];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) store_acc_T<T>(rA, S::LDPK, jt * 16, it * 16, p[jt][it]);
-        __syncthreads();
-        f32x4 o[G::DT][4];
-        zero_acc(o);
+        for (int m = 0; m < G::DT; ++m) o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
             for (int c = 0; c < G::JC; ++c) {
-                uint4 av[G::DT], bp[4];
+                const uint4 bp = frag_kc(rA, S::LDPK, w * 16, kt * G::JC + c);
 #pragma unroll
-                for (int m = 0; m < G::DT; ++m) av[m] = frag_km<T>(rV + kt * G::TILE_D, G::LDR, m * 16, c);
-#pragma unroll
-                for (int n = 0; n < 4; ++n) bp[n] = frag_kc(rA, S::LDPK, n * 16, kt * G::JC + c);
-#pragma unroll
-                for (int m = 0; m < G::DT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) mma_chunk<T>(o[m][n], av[m], bp[n]);
+                for (int m = 0; m < G::DT; ++m) mma_chunk<T>(o[m], frag_km<T>(rV + kt * G::TILE_D, G::LDR, m * 16, c), bp);
             }
-        __syncthreads();
 #pragma unroll
-        for (int m = 0; m < G::DT; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) store_acc_T<T>(rB, G::LDR, m * 16, n * 16, o[m][n]);      // O [i][d]
-        __syncthreads();
-        store_tile<T, D>(rB, a.out, a.ldo, nq, wy, wx, a.H, a.W, a.shift, h * D);
-        __syncthreads();
+        for (int m = 0; m < G::DT; ++m) store_acc_T<T>(rB, G::LDR, m * 16, w * 16, o[m]);      // O [i][d], own rows
+        wave_fence();
+        store_rows16<T, D>(rB, a.out, a.ldo, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+        __syncthreads();                    // before the next item's tiles overwrite what slower waves still read
     }
 }
 
@@ -415,164 +392,148 @@ template <typename T, int D, int NKT, int LFS> struct SmemB {
     static constexpr int SCR = 2 * 64 * G::LDV > 64 * G::LDP ? 2 * 64 * G::LDV : 64 * G::LDP;   // >= one [64][64] tile
     static constexpr int OFF_Q = 0, OFF_DO = G::TILE_D, OFF_K = 2 * G::TILE_D, OFF_V = 3 * G::TILE_D;
     static constexpr int OFF_X = 4 * G::TILE_D, OFF_Y = OFF_X + SCR;
-    static constexpr int OFF_DB = OFF_Y + SCR;                                                 // float [NKT][64][64]
-    static constexpr int OFF_DI = OFF_DB + NKT * 64 * 64 * 4;                                  // float [64]
-    static constexpr int OFF_BIN = OFF_DI + 256;                                               // float [225] (+pad)
+    static constexpr int OFF_BIN = OFF_Y + SCR;                                                // float [225] (+pad)
     static constexpr int BYTES = OFF_BIN + 1024;
 };
 
 template <typename T, int D, int NKT, int LFS>
-__global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(NTH, 2) void attn_bwd_kernel(AttnArgs a) {
     using G = Geo<T, D>;
     using S = SmemB<T, D, NKT, LFS>;
-    constexpr int SZ = G::SZ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sQ = smem + S::OFF_Q; char* sDO = smem + S::OFF_DO; char* sK = smem + S::OFF_K; char* sV = smem + S::OFF_V;
     char* sX = smem + S::OFF_X; char* sY = smem + S::OFF_Y;
-    float* sDB = reinterpret_cast<float*>(smem + S::OFF_DB);
-    float* sDI = reinterpret_cast<float*>(smem + S::OFF_DI);
-    const int l = lane_id();
+    const int l = lane_id(), w = wave_id();
     const int nWx = a.W / 8, nWy = a.H / 8, nW = nWx * nWy;
     // grid: x = chunk, y = head, z = query band
     const int h = blockIdx.y, lq = blockIdx.z;
-    for (int idx = l; idx < NKT * 4096; idx += 64) sDB[idx] = 0.f;
-    __syncthreads();
+    const int i = w * 16 + (l & 15);                         // the query of this lane's score columns
+    f32x4 dbacc[NKT][4];                                     // bias-gradient accumulators of (i, j = 16 jt + 4 (l>>4) + r), all windows
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) dbacc[kt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int win = blockIdx.x; win < a.nwin; win += gridDim.x) {
-        const int b = win / nW, w = win % nW, wy = w / nWx, wx = w % nWx;
+        const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
         const bool last_y = wy == nWy - 1, last_x = wx == nWx - 1;
         const int nq = lq * a.B + b;
         const size_t item = ((size_t)win * a.L + lq) * a.heads + h;
         load_tile<T, D>(sQ, a.q, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
         load_tile<T, D>(sDO, a.dout, a.lddo, nq, wy, wx, a.H, a.W, a.shift, h * D);
-        float lse[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) lse[it] = a.lse[item * 64 + it * 16 + (l & 15)];
-        float di[4] = {0.f, 0.f, 0.f, 0.f};
+        const float lse = a.lse[item * 64 + i];
+        float di = 0.f;
         if constexpr (NKT > 1) {
-            // D_i = sum_d O[i][d] dO[i][d]   (rowsum(P o dP) == rowsum(O o dO) when P' = P)
-            const long row = token_row(nq, wy, wx, l, a.H, a.W, a.shift);
+            // D_i = sum_d O[i][d] dO[i][d]   (rowsum(P o dP) == rowsum(O o dO) when P' = P); the 4 lanes of a column share the row
+            const long row = token_row(nq, wy, wx, i, a.H, a.W, a.shift);
             const T* op = reinterpret_cast<const T*>(a.out) + row * a.ldo + h * D;
             const T* gp = reinterpret_cast<const T*>(a.dout) + row * a.lddo + h * D;
             float s = 0.f;
-            for (int d = 0; d < D; ++d) s += TT<T>::ld(op + d) * TT<T>::ld(gp + d);
-            sDI[l] = s;
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < 4; ++it) di[it] = sDI[it * 16 + (l & 15)];
+            for (int d = (l >> 4); d < D; d += 4) s += TT<T>::ld(op + d) * TT<T>::ld(gp + d);
+            di = col_reduce_sum(s);
         }
-        f32x4 dq[G::DT][4];
-        zero_acc(dq);
+        f32x4 dq[G::DT];
+#pragma unroll
+        for (int m = 0; m < G::DT; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int kt = 0; kt < NKT; ++kt) {
             const int lk = a.mode == 0 ? lq : other_band(lq, kt);
             const int nk = lk * a.B + b;
             const int tabid = lq * a.L + lk;
-            __syncthreads();
+            __syncthreads();                                 // every wave is done with the previous K / V tiles and scratch
             load_tile<T, D>(sK, a.k, a.ld, nk, wy, wx, a.H, a.W, a.shift, h * D);
             load_tile<T, D>(sV, a.v, a.ld, nk, wy, wx, a.H, a.W, a.shift, h * D);
             __syncthreads();
-            // P^T[j][i] = exp(scale * K Q^T + bias + mask - lse_i)
-            f32x4 p[4][4], dp[4][4];
+            // P^T[j][i] = exp(scale * K Q^T + bias + mask - lse_i), own columns i
+            f32x4 p[4], dp[4];
             const float* tab = a.bias + (size_t)tabid * 225 * a.heads;
             auto compute_p = [&]() {
-                asm volatile("" ::: "memory");            // do not keep the 64 gathered bias values live across the band filter
-                zero_acc(p);
-                mma_tiles<T, 4, 4>(p, sK, G::LDR, 0, sQ, G::LDR, 0, G::KC);
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int i = it * 16 + (l & 15);
+                for (int jt = 0; jt < 4; ++jt) p[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt)
+                for (int c = 0; c < G::KC; ++c) {
+                    const uint4 bq = frag_kc(sQ, G::LDR, w * 16, c);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int j = jt * 16 + ((l >> 4) << 2) + r;
-                            p[jt][it][r] = __expf(p[jt][it][r] * a.scale + bias_mask(tab, a.heads, h, i, j, a.shift, last_y, last_x) - lse[it]);
-                        }
+                    for (int m = 0; m < 4; ++m) mma_chunk<T>(p[m], frag_kc(sK, G::LDR, m * 16, c), bq);
                 }
-            };
-            compute_p();
-            float ca = 1.f, cc = 0.f;
-            if constexpr (LFS >= 1) {
-                const float* cf = a.coef + ((size_t)b * a.heads + h) * 3;
-                ca = cf[0]; const float cb = cf[1]; cc = cf[2];
-                // P'^T = a P^T + b (+ c B1(P)^T)  -> sX as [j][i] (k = i contiguous)
-                if constexpr (LFS == 2) {
-                    f32x4 f[4][4];
-                    band_filter<T>(p, f, sX, sY, a.lfs);
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                        for (int it = 0; it < 4; ++it) store_acc_N<T>(sX, G::LDP, jt * 16, it * 16, p[jt][it] * ca + cb + f[jt][it] * cc);
-                } else {
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                        for (int it = 0; it < 4; ++it) store_acc_N<T>(sX, G::LDP, jt * 16, it * 16, p[jt][it] * ca + cb);
-                }
-            } else {
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) store_acc_N<T>(sX, G::LDP, jt * 16, it * 16, p[jt][it]);
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = jt * 16 + ((l >> 4) << 2) + r;
+                        p[jt][r] = __expf(p[jt][r] * a.scale + bias_mask(tab, a.heads, h, i, j, a.shift, last_y, last_x) - lse);
+                    }
+            };
+            compute_p();
+            float ca = 1.f, cc = 0.f;
+            // P'[i][j] = a P + b (+ c B1(P))  -> sX rows i of the own strip
+            if constexpr (LFS >= 1) {
+                const float* cf = a.coef + ((size_t)b * a.heads + h) * 3;
+                ca = cf[0]; const float cb = cf[1]; cc = cf[2];
+                if constexpr (LFS == 2) {
+                    f32x4 f[4];
+                    band_filter<T>(p, f, sX, sY, a.lfs);
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) store_acc_T<T>(sX, G::LDP, jt * 16, w * 16, p[jt] * ca + cb + f[jt] * cc);
+                } else {
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) store_acc_T<T>(sX, G::LDP, jt * 16, w * 16, p[jt] * ca + cb);
+                }
+            } else {
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) store_acc_T<T>(sX, G::LDP, jt * 16, w * 16, p[jt]);
             }
             __syncthreads();
-            // dV^T[d][j] = sum_i dO[i][d] P'[i][j]   (A = dO read k-major, B = P'^T rows j)
+            // dV^T[d][j] = sum_i dO[i][d] P'[i][j], own columns j  (both operands read along the token axis: transposing reads)
             {
-                f32x4 dv[G::DT][4];
-                zero_acc(dv);
+                f32x4 dv[G::DT];
+#pragma unroll
+                for (int m = 0; m < G::DT; ++m) dv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
                 for (int c = 0; c < G::JC; ++c) {
-                    uint4 am[G::DT], bn[4];
+                    const uint4 bn = frag_km<T>(sX, G::LDP, w * 16, c);
 #pragma unroll
-                    for (int m = 0; m < G::DT; ++m) am[m] = frag_km<T>(sDO, G::LDR, m * 16, c);
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) bn[n] = frag_kc(sX, G::LDP, n * 16, c);
-#pragma unroll
-                    for (int m = 0; m < G::DT; ++m)
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) mma_chunk<T>(dv[m][n], am[m], bn[n]);
+                    for (int m = 0; m < G::DT; ++m) mma_chunk<T>(dv[m], frag_km<T>(sDO, G::LDR, m * 16, c), bn);
                 }
-                __syncthreads();
 #pragma unroll
-                for (int m = 0; m < G::DT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) store_acc_T<T>(sY, G::LDR, m * 16, n * 16, dv[m][n]);   // dV [j][d]
-                __syncthreads();
+                for (int m = 0; m < G::DT; ++m) store_acc_T<T>(sY, G::LDR, m * 16, w * 16, dv[m]);   // dV [j][d], own rows j
+                wave_fence();
                 char* dvp = (NKT > 1 && kt_slot(lq, lk) == 1) ? a.dv2 : a.dv;
-                store_tile<T, D>(sY, dvp, a.ldd, nk, wy, wx, a.H, a.W, a.shift, h * D);
-                __syncthreads();
+                store_rows16<T, D>(sY, dvp, a.ldd, nk, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
             }
-            // dP'^T[j][i] = sum_d V[j][d] dO[i][d]   (after dV: P' and its scratch are dead, keeps the live set small)
-            zero_acc(dp);
-            mma_tiles<T, 4, 4>(dp, sV, G::LDR, 0, sDO, G::LDR, 0, G::KC);
+            // dP'^T[j][i] = sum_d V[j][d] dO[i][d], own columns i
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < G::KC; ++c) {
+                const uint4 bd = frag_kc(sDO, G::LDR, w * 16, c);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) mma_chunk<T>(dp[m], frag_kc(sV, G::LDR, m * 16, c), bd);
+            }
+            __syncthreads();                                 // every wave is done reading P' (sX) and its dV staging rows (sY)
             if constexpr (LFS >= 1) {
                 // G^T = B1(dP')^T ; d(a,b,c) = (<dP',P>, sum dP', <G,P>) ; dP = a dP' + c G
                 float s1 = 0.f, s2 = 0.f, s3 = 0.f;
                 if constexpr (LFS == 2) {
-                    f32x4 g[4][4];
+                    f32x4 g[4];
                     band_filter<T>(dp, g, sX, sY, a.lfs);
-                    compute_p();                              // P is cheaper to rebuild (32 MFMA) than to keep live across the filter
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                        for (int it = 0; it < 4; ++it)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                s1 += dp[jt][it][r] * p[jt][it][r];
-                                s2 += dp[jt][it][r];
-                                s3 += g[jt][it][r] * p[jt][it][r];
-                                dp[jt][it][r] = dp[jt][it][r] * ca + g[jt][it][r] * cc;
-                            }
+                        for (int r = 0; r < 4; ++r) {
+                            s1 += dp[jt][r] * p[jt][r];
+                            s2 += dp[jt][r];
+                            s3 += g[jt][r] * p[jt][r];
+                            dp[jt][r] = dp[jt][r] * ca + g[jt][r] * cc;
+                        }
                 } else {
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                        for (int it = 0; it < 4; ++it)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                s1 += dp[jt][it][r] * p[jt][it][r];
-                                s2 += dp[jt][it][r];
-                                dp[jt][it][r] = dp[jt][it][r] * ca;
-                            }
+                        for (int r = 0; r < 4; ++r) {
+                            s1 += dp[jt][r] * p[jt][r];
+                            s2 += dp[jt][r];
+                            dp[jt][r] = dp[jt][r] * ca;
+                        }
                 }
                 s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
                 if (l == 0) {
@@ -581,87 +542,69 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
                 }
             }
             // D_i (NKT == 1: straight from registers), dS^T = P^T o (dP^T - D_i)
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                if constexpr (NKT == 1) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) s += p[jt][it][r] * dp[jt][it][r];
-                    di[it] = col_reduce_sum(s);
-                }
+            if constexpr (NKT == 1) {
+                float s = 0.f;
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float ds = p[jt][it][r] * (dp[jt][it][r] - di[it]);
-                        dp[jt][it][r] = ds;
-                        sDB[kt * 4096 + (it * 16 + (l & 15)) * 64 + jt * 16 + ((l >> 4) << 2) + r] += ds;
-                    }
+                    for (int r = 0; r < 4; ++r) s += p[jt][r] * dp[jt][r];
+                di = col_reduce_sum(s);
             }
-            // dS -> sX as [i][j] (transposed store, k = j) and sY as [j][i] (plain store, k = i)
-            __syncthreads();
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
+            for (int jt = 0; jt < 4; ++jt) {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    store_acc_T<T>(sX, G::LDP, jt * 16, it * 16, dp[jt][it]);
-                    store_acc_N<T>(sY, G::LDP, jt * 16, it * 16, dp[jt][it]);
-                }
+                for (int r = 0; r < 4; ++r) dp[jt][r] = p[jt][r] * (dp[jt][r] - di);
+                if (NKT == 1 || kt == 0) dbacc[0][jt] += dp[jt]; else dbacc[NKT - 1][jt] += dp[jt];   // static indices: registers
+            }
+            // dS -> sX as [i][j], rows i of the own strip; dQ reads it along j (row fragments), dK along i (transposing reads)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) store_acc_T<T>(sX, G::LDP, jt * 16, w * 16, dp[jt]);
             __syncthreads();
-            // dQ^T[d][i] += sum_j K[j][d] dS[i][j] ;  dK^T[d][j] = sum_i Q[i][d] dS[i][j]
-            f32x4 dk[G::DT][4], dql[G::DT][4];
-            zero_acc(dk);
-            zero_acc(dql);
+            // dQ^T[d][i] += sum_j K[j][d] dS[i][j] (own i) ;  dK^T[d][j] = sum_i Q[i][d] dS[i][j] (own j)
+            f32x4 dk[G::DT];
+#pragma unroll
+            for (int m = 0; m < G::DT; ++m) dk[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
             for (int c = 0; c < G::JC; ++c) {
-                uint4 ak[G::DT], aq[G::DT], bx[4], by[4];
+                const uint4 bx = frag_kc(sX, G::LDP, w * 16, c), by = frag_km<T>(sX, G::LDP, w * 16, c);
 #pragma unroll
-                for (int m = 0; m < G::DT; ++m) { ak[m] = frag_km<T>(sK, G::LDR, m * 16, c); aq[m] = frag_km<T>(sQ, G::LDR, m * 16, c); }
-#pragma unroll
-                for (int n = 0; n < 4; ++n) { bx[n] = frag_kc(sX, G::LDP, n * 16, c); by[n] = frag_kc(sY, G::LDP, n * 16, c); }
-#pragma unroll
-                for (int m = 0; m < G::DT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) { mma_chunk<T>(dql[m][n], ak[m], bx[n]); mma_chunk<T>(dk[m][n], aq[m], by[n]); }
+                for (int m = 0; m < G::DT; ++m) {
+                    mma_chunk<T>(dq[m], frag_km<T>(sK, G::LDR, m * 16, c), bx);
+                    mma_chunk<T>(dk[m], frag_km<T>(sQ, G::LDR, m * 16, c), by);
+                }
             }
 #pragma unroll
-            for (int m = 0; m < G::DT; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) dq[m][n] += dql[m][n];
-            __syncthreads();
-#pragma unroll
-            for (int m = 0; m < G::DT; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) store_acc_T<T>(sX, G::LDR, m * 16, n * 16, dk[m][n] * a.scale);   // dK [j][d]
-            __syncthreads();
+            for (int m = 0; m < G::DT; ++m) store_acc_T<T>(sY, G::LDR, m * 16, w * 16, dk[m] * a.scale);   // dK [j][d], own rows j
+            wave_fence();
             char* dkp = (NKT > 1 && kt_slot(lq, lk) == 1) ? a.dk2 : a.dk;
-            store_tile<T, D>(sX, dkp, a.ldd, nk, wy, wx, a.H, a.W, a.shift, h * D);
+            store_rows16<T, D>(sY, dkp, a.ldd, nk, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
         }
-        __syncthreads();
+        __syncthreads();                                     // sX / sY / sQ / sDO are free: all waves are past their last reads
 #pragma unroll
-        for (int m = 0; m < G::DT; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) store_acc_T<T>(sY, G::LDR, m * 16, n * 16, dq[m][n] * a.scale);         // dQ [i][d]
-        __syncthreads();
-        store_tile<T, D>(sY, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D);
-        __syncthreads();
+        for (int m = 0; m < G::DT; ++m) store_acc_T<T>(sY, G::LDR, m * 16, w * 16, dq[m] * a.scale);         // dQ [i][d], own rows i
+        wave_fence();
+        store_rows16<T, D>(sY, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+        // the next window's Q / dO loads touch neither sY nor anything a wave still reads
     }
-    // flush the bias-gradient accumulators: fold the 64x64 pairs into the 225 relative positions on chip, then one
+    // flush the bias-gradient accumulators: fold the (i, j) pairs into the 225 relative positions on chip, then one
     // atomic per bin into the parameter layout [table][225][heads] (all workgroups of a head hit the same 225 words)
     float* bins = reinterpret_cast<float*>(smem + S::OFF_BIN);
+#pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         __syncthreads();
-        for (int idx = l; idx < 225; idx += 64) bins[idx] = 0.f;
+        for (int idx = threadIdx.x; idx < 225; idx += NTH) bins[idx] = 0.f;
         __syncthreads();
-        for (int idx = l; idx < 4096; idx += 64) {
-            const int i = idx >> 6, j = idx & 63;
-            atomicAdd(&bins[((i >> 3) - (j >> 3) + 7) * 15 + (i & 7) - (j & 7) + 7], sDB[kt * 4096 + idx]);
-        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + ((l >> 4) << 2) + r;
+                atomicAdd(&bins[((i >> 3) - (j >> 3) + 7) * 15 + (i & 7) - (j & 7) + 7], dbacc[kt][jt][r]);
+            }
         __syncthreads();
         const int lk = a.mode == 0 ? lq : other_band(lq, kt);
         float* dst = a.dbias + (size_t)(lq * a.L + lk) * 225 * a.heads;
-        for (int idx = l; idx < 225; idx += 64) atomicAdd(dst + idx * a.heads + h, bins[idx]);
+        for (int idx = threadIdx.x; idx < 225; idx += NTH) atomicAdd(dst + idx * a.heads + h, bins[idx]);
     }
 }
 
@@ -676,7 +619,7 @@ int fwd_launch(const AttnArgs& a, hipStream_t st) {
         done = true;
     }
     const int items = a.nwin * a.L * a.heads;
-    hipLaunchKernelGGL((attn_fwd_kernel<T, D, NKT, LFS>), dim3(items < 8192 ? items : 8192), dim3(64), S::FWD_BYTES, st, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, D, NKT, LFS>), dim3(items < 4096 ? items : 4096), dim3(NTH), S::FWD_BYTES, st, a);
     FW_LAUNCH_RET();
 }
 template <typename T, int D, int NKT, int LFS>
@@ -688,7 +631,7 @@ int bwd_launch(const AttnArgs& a, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, S::BYTES);
         done = true;
     }
-    hipLaunchKernelGGL((attn_bwd_kernel<T, D, NKT, LFS>), dim3(a.chunks, a.heads, a.L), dim3(64), S::BYTES, st, a);
+    hipLaunchKernelGGL((attn_bwd_kernel<T, D, NKT, LFS>), dim3(a.chunks, a.heads, a.L), dim3(NTH), S::BYTES, st, a);
     FW_LAUNCH_RET();
 }
 
@@ -752,7 +695,7 @@ extern "C" int fw_attn_bwd(int dtype, int D, int nkt, int lfs, const void* q, co
     a.nwin = B * (H / 8) * (W / 8);
     a.dout = (const char*)dout; a.lddo = lddo; a.dq = (char*)dq; a.dk = (char*)dk; a.dv = (char*)dv;
     a.dk2 = (char*)dk2; a.dv2 = (char*)dv2; a.ldd = ldd; a.dbias = dbias; a.dcoef = dcoef;
-    int chunks = 2048 / (heads * L);
+    int chunks = 1024 / (heads * L);          // 4-wave workgroups, 2 per CU: about two rounds of the chip
     if (chunks < 1) chunks = 1;
     if (chunks > a.nwin) chunks = a.nwin;
     a.chunks = chunks;

@@ -130,13 +130,18 @@ template <> FW_SPEC uint4 frag_km<float>(const char* tile, int ldb, int m0, int 
     r.w = *reinterpret_cast<const unsigned*>(p + 3 * ldb);
     return r;
 }
+// bf16: gfx950's transposing LDS read.  ds_read_b64_tr_b16 hands lane i of each 16-lane group column i of a 4-row x
+// 16-column block (row q in element q); lane 4q+p supplies the address of row q, columns 4p..4p+3.  Two reads (k rows
+// 8g..8g+3 and 8g+4..8g+7 of the chunk) are exactly the 8 k-values of the 16x16x32 fragment.  Needs EXEC = all ones
+// (call from wave-uniform code only), 8-byte aligned addresses (ldb % 8 == 0, m0 % 4 == 0).
+typedef __attribute__((ext_vector_type(4))) short fw_s16x4;
+typedef __attribute__((address_space(3))) fw_s16x4 fw_lds_s16x4;
 template <> FW_SPEC uint4 frag_km<bf16raw>(const char* tile, int ldb, int m0, int chunk) {
     const int l = lane_id();
-    const char* p = tile + (chunk * 32 + ((l >> 4) << 3)) * ldb + (m0 + (l & 15)) * 2;
-    unsigned e[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = *reinterpret_cast<const unsigned short*>(p + j * ldb);
-    return make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    const char* p = tile + (chunk * 32 + ((l >> 4) << 3) + ((l >> 2) & 3)) * ldb + (m0 + ((l & 3) << 2)) * 2;
+    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((fw_lds_s16x4*)p));
+    const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((fw_lds_s16x4*)(p + 4 * ldb)));
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
 // Store one C/D tile.  acc element r of lane l is C[row0 + 4*(l>>4) + r][col0 + (l&15)].

@@ -16,6 +16,7 @@
 // with 4 CONSECUTIVE n for one m: bias / residual / output are 8- and 16-byte vector accesses.
 // bf16 uses v_mfma_f32_16x16x32_bf16, f32 uses v_mfma_f32_16x16x4_f32 (exact f32), same code.
 #include "fw_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -50,6 +51,58 @@ template <typename T> FW_DEV uint4 apply_gelu16(const uint4& v) {
 #pragma unroll
     for (int i = 0; i < TT<T>::E16; ++i) f[i] = gelu_f(f[i]);
     return pack16<T>(f);
+}
+
+// ---- epilogue of one lane: 4 consecutive n of row m ------------------------------------------
+template <typename T>
+FW_DEV void epi_quad(const GemmArgs& a, const f32x4& acc, int m, int n0, float rs, int z) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] * a.alpha;
+    if (a.bias && z == 0) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += b[r];
+    }
+    if (a.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = lrelu_f(v[r], a.slope);
+    } else if (a.act == 2) {
+        const T* ap = reinterpret_cast<const T*>(a.aux) + (long)m * a.ldaux + n0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(TT<T>::ld(ap + r));
+    } else if (a.act == 3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+    }
+    if (a.rowscale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= rs;
+    }
+    if (a.residual && z == 0) {
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(a.residual + (long)m * a.ldr + n0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rr[r];
+    }
+    if (a.C2) {
+        T* c2 = reinterpret_cast<T*>(a.C2) + (long)m * a.ldc2 + n0;
+        const float g0 = gelu_f(v[0]), g1 = gelu_f(v[1]), g2 = gelu_f(v[2]), g3 = gelu_f(v[3]);
+        if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(c2) = f32x4{g0, g1, g2, g3};
+        else *reinterpret_cast<uint2*>(c2) = make_uint2(pack_bf2(g0, g1), pack_bf2(g2, g3));
+    }
+    if (a.out_f32) {
+        float* cp = reinterpret_cast<float*>(a.C) + (long)z * a.c_zstride + (long)m * a.ldc + n0;
+        if (a.accumulate && a.c_zstride == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
+        } else {
+            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    } else {
+        T* cp = reinterpret_cast<T*>(a.C) + (long)m * a.ldc + n0;
+        if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+        else *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    }
 }
 
 // ---- operand staging -----------------------------------------------------------------------
@@ -274,109 +327,191 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         }
     }
     // ---- epilogue: lane holds C[m][n0..n0+3], m = col of the MFMA tile, n = rows -------------
-    // bf16 outputs are staged through LDS ([m][n] rows, 16-byte slots XOR-swizzled by row) and written back as whole
-    // rows, 16 bytes per lane with consecutive lanes along n -- the direct form is 8 bytes per lane, 16 rows per store.
+    // (an LDS-staged, row-coalesced form of these stores measured ~20 % slower on MI355X: L2 merges the 8-byte pieces)
     const int l = lane_id();
-    constexpr int SROW = BN * 2, SLOTS = SROW / 16, SMASK = SLOTS >= 16 ? 15 : SLOTS - 1;
-    bool staged = false;
-    if constexpr (sizeof(T) == 2) {
-        // measured on MI355X (tools/gemm_bench.py): the staged form is ~20 % SLOWER on every shape of the step -- L2 merges the
-        // 8-byte row pieces fine and the extra barrier + LDS pass costs more than it saves.  Kept for reference, disabled.
-        staged = false && !a.out_f32 && ((uintptr_t)a.C & 15) == 0 && (a.ldc & 7) == 0 &&
-                 (!a.C2 || (((uintptr_t)a.C2 & 15) == 0 && (a.ldc2 & 7) == 0));
-    }
-    char* st1 = smem;                                    // [BM][BN] bf16 for C
-    char* st2 = smem + BM * SROW;                        // [BM][BN] bf16 for C2
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt) {
-        const int ml = wm0 + mt * 16 + (l & 15);
-        const int m = m_blk + ml;
+        const int m = m_blk + wm0 + mt * 16 + (l & 15);
         if (m >= a.M) continue;
         const float rs = a.rowscale ? a.rowscale[m / a.rows_per_scale] : 1.0f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
             if (n0 >= a.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[nt][mt][r] * a.alpha;
-            if (a.bias && blockIdx.z == 0) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += b[r];
-            }
-            if (a.act == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = lrelu_f(v[r], a.slope);
-            } else if (a.act == 2) {
-                const T* ap = reinterpret_cast<const T*>(a.aux) + (long)m * a.ldaux + n0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(TT<T>::ld(ap + r));
-            } else if (a.act == 3) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-            }
-            if (a.rowscale) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= rs;
-            }
-            if (a.residual && blockIdx.z == 0) {
-                const f32x4 rr = *reinterpret_cast<const f32x4*>(a.residual + (long)m * a.ldr + n0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += rr[r];
-            }
-            if (staged) {
-                const int nl = wn0 + nt * 16 + ((l >> 4) << 2);                 // column inside the tile
-                const int off = ml * SROW + ((((nl * 2) >> 4) ^ (ml & SMASK)) << 4) + ((nl * 2) & 8);
-                *reinterpret_cast<uint2*>(st1 + off) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                if (a.C2) *reinterpret_cast<uint2*>(st2 + off) = make_uint2(pack_bf2(gelu_f(v[0]), gelu_f(v[1])), pack_bf2(gelu_f(v[2]), gelu_f(v[3])));
-                continue;
-            }
-            if (a.C2) {
-                T* c2 = reinterpret_cast<T*>(a.C2) + (long)m * a.ldc2 + n0;
-                const float g0 = gelu_f(v[0]), g1 = gelu_f(v[1]), g2 = gelu_f(v[2]), g3 = gelu_f(v[3]);
-                if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(c2) = f32x4{g0, g1, g2, g3};
-                else *reinterpret_cast<uint2*>(c2) = make_uint2(pack_bf2(g0, g1), pack_bf2(g2, g3));
-            }
-            if (a.out_f32) {
-                float* cp = reinterpret_cast<float*>(a.C) + (long)blockIdx.z * a.c_zstride + (long)m * a.ldc + n0;
-                if (a.accumulate && a.c_zstride == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
-                } else {
-                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+            epi_quad<T>(a, acc[nt][mt], m, n0, rs, blockIdx.z);
+        }
+    }
+}
+
+// =====================================================================================================
+// W-stationary streaming kernel for TALL-SKINNY products: M = tokens (10^4 .. 10^6), K * sizeof(T) <= 512 bytes.
+// These are HBM-bound (C <= 224 stages of the U-Net: 45 .. 180 FLOP/B against a ridge of ~310), and the tiled
+// kernel above spends its time in fill / barrier / drain of one or two K steps at 2 waves per SIMD.  Here
+//   * a workgroup (8 waves) stages its W panel [bnp columns][K] ONCE into LDS (k-contiguous, transposing if needed),
+//   * then every wave streams 32-row strips of X on its own: the MFMA B-fragments are loaded STRAIGHT from global
+//     memory into registers (16 B per lane, k-contiguous rows -- no LDS, no barrier), X is read exactly once for
+//     all columns of the panel, and the strip after next is requested before the epilogue of the current one.
+// 2 workgroups = 16 independent waves per CU keep loads, MFMAs and stores of different strips in flight together.
+template <typename T, int NCH, bool WT>
+__global__ __launch_bounds__(512, 2) void gemm_stream_kernel(GemmArgs a, int bnp) {
+    constexpr int SZ = TT<T>::SZ, E = TT<T>::E16;
+    constexpr int RL = NCH * 64;                          // bytes of K per LDS row (NCH even: whole 128-byte swizzle groups)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int l = lane_id(), wave = threadIdx.x >> 6;
+    const int n_blk = blockIdx.y * bnp;
+    const int kbytes = a.K * SZ;
+
+    // ---- stage the W panel: LDS row = output column n, zero past K and past N -----------------------
+    if constexpr (!WT) {
+        constexpr int SLOTS = RL / 16;
+        for (int idx = threadIdx.x; idx < bnp * SLOTS; idx += 512) {
+            const int row = idx / SLOTS, kb = (idx % SLOTS) * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (n_blk + row < a.N && kb < kbytes) {
+                v = *reinterpret_cast<const uint4*>(a.W + (long)(n_blk + row) * a.ldw * SZ + kb);
+                const int valid = kbytes - kb;
+                if (valid < 16) {
+                    if (valid <= 12) v.w = 0;
+                    if (valid <= 8) v.z = 0;
+                    if (valid <= 4) v.y = 0;
                 }
+            }
+            *reinterpret_cast<uint4*>(smem + row * RL + (kb ^ swz(row))) = v;
+        }
+    } else {
+        // W is [K][N] (n contiguous): a thread takes 4 k-rows x E columns and writes E rows x 4 k (8 or 16 bytes)
+        constexpr int KQ = RL / (4 * SZ);
+        const int nblocks = bnp / E;
+        for (int idx = threadIdx.x; idx < KQ * nblocks; idx += 512) {
+            const int ib = idx % nblocks, kq = idx / nblocks;
+            uint4 r[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = kq * 4 + kk;
+                r[kk] = make_uint4(0, 0, 0, 0);
+                if (k < a.K && n_blk + ib * E < a.N) r[kk] = *reinterpret_cast<const uint4*>(a.W + ((long)k * a.ldw + n_blk + ib * E) * SZ);
+            }
+            if constexpr (sizeof(T) == 4) {
+                const int r0 = ib * 4, cb = kq * 16;
+                *reinterpret_cast<uint4*>(smem + (r0 + 0) * RL + (cb ^ swz(r0 + 0))) = make_uint4(r[0].x, r[1].x, r[2].x, r[3].x);
+                *reinterpret_cast<uint4*>(smem + (r0 + 1) * RL + (cb ^ swz(r0 + 1))) = make_uint4(r[0].y, r[1].y, r[2].y, r[3].y);
+                *reinterpret_cast<uint4*>(smem + (r0 + 2) * RL + (cb ^ swz(r0 + 2))) = make_uint4(r[0].z, r[1].z, r[2].z, r[3].z);
+                *reinterpret_cast<uint4*>(smem + (r0 + 3) * RL + (cb ^ swz(r0 + 3))) = make_uint4(r[0].w, r[1].w, r[2].w, r[3].w);
             } else {
-                T* cp = reinterpret_cast<T*>(a.C) + (long)m * a.ldc + n0;
-                if (sizeof(T) == 4) {
-                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-                    *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                const int r0 = ib * 8, cb = kq * 8;
+                const unsigned w0[4] = {r[0].x, r[0].y, r[0].z, r[0].w};
+                const unsigned w1[4] = {r[1].x, r[1].y, r[1].z, r[1].w};
+                const unsigned w2[4] = {r[2].x, r[2].y, r[2].z, r[2].w};
+                const unsigned w3[4] = {r[3].x, r[3].y, r[3].z, r[3].w};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint2 lo = make_uint2(__builtin_amdgcn_perm(w1[d], w0[d], 0x05040100u), __builtin_amdgcn_perm(w3[d], w2[d], 0x05040100u));
+                    const uint2 hi = make_uint2(__builtin_amdgcn_perm(w1[d], w0[d], 0x07060302u), __builtin_amdgcn_perm(w3[d], w2[d], 0x07060302u));
+                    *reinterpret_cast<uint2*>(smem + (r0 + 2 * d) * RL + (cb ^ swz(r0 + 2 * d))) = lo;
+                    *reinterpret_cast<uint2*>(smem + (r0 + 2 * d + 1) * RL + (cb ^ swz(r0 + 2 * d + 1))) = hi;
                 }
             }
         }
     }
-    if constexpr (sizeof(T) == 2) {
-        if (staged) {                                    // block-uniform
-            __syncthreads();
-            for (int c = threadIdx.x; c < BM * SLOTS; c += 256) {
-                const int row = c / SLOTS, slot = c % SLOTS;
-                const int m = m_blk + row, n = n_blk + slot * 8;
-                if (m >= a.M || n >= a.N) continue;
-                const int off = row * SROW + ((slot ^ (row & SMASK)) << 4);
-                const uint4 v1 = *reinterpret_cast<const uint4*>(st1 + off);
-                bf16raw* cp = reinterpret_cast<bf16raw*>(a.C) + (long)m * a.ldc + n;
-                if (n + 8 <= a.N) *reinterpret_cast<uint4*>(cp) = v1;
-                else *reinterpret_cast<uint2*>(cp) = make_uint2(v1.x, v1.y);           // N % 8 == 4 tail
-                if (a.C2) {
-                    const uint4 v2 = *reinterpret_cast<const uint4*>(st2 + off);
-                    bf16raw* c2 = reinterpret_cast<bf16raw*>(a.C2) + (long)m * a.ldc2 + n;
-                    if (n + 8 <= a.N) *reinterpret_cast<uint4*>(c2) = v2;
-                    else *reinterpret_cast<uint2*>(c2) = make_uint2(v2.x, v2.y);
+    __syncthreads();                                      // the only barrier: from here on the waves run independently
+
+    const int strips = (a.M + 31) >> 5;
+    const int stride = gridDim.x * 8;
+    const int ncols = min(bnp, a.N - n_blk);
+    const int nnb = (ncols + 63) >> 6;
+    uint4 xf[2][NCH];
+    auto load_x = [&](int strip) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int row = strip * 32 + mt * 16 + (l & 15);
+            const char* src = a.X + (long)row * a.ldx * SZ + ((l >> 4) << 4);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int kb = c * 64 + ((l >> 4) << 4);
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (row < a.M && kb < kbytes) {
+                    v = *reinterpret_cast<const uint4*>(src + c * 64);
+                    const int valid = kbytes - kb;
+                    if (valid < 16) {
+                        if (valid <= 12) v.w = 0;
+                        if (valid <= 8) v.z = 0;
+                        if (valid <= 4) v.y = 0;
+                    }
+                }
+                xf[mt][c] = v;
+            }
+        }
+    };
+    int strip = blockIdx.x * 8 + wave;
+    if (strip < strips) load_x(strip);
+    for (; strip < strips; strip += stride) {
+        const int m_lane = strip * 32 + (l & 15);
+        float rs[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = m_lane + mt * 16;
+            rs[mt] = (a.rowscale && m < a.M) ? a.rowscale[m / a.rows_per_scale] : 1.0f;
+        }
+#pragma unroll 1
+        for (int nb = 0; nb < nnb; ++nb) {
+            f32x4 acc[4][2];
+            zero_acc(acc);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                uint4 af[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = nb * 64 + i * 16 + (l & 15);
+                    af[i] = *reinterpret_cast<const uint4*>(smem + row * RL + ((c * 64 + ((l >> 4) << 4)) ^ swz(row)));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    mma_chunk<T>(acc[i][0], af[i], xf[0][c]);
+                    mma_chunk<T>(acc[i][1], af[i], xf[1][c]);
+                }
+            }
+            if (nb == nnb - 1 && strip + stride < strips) load_x(strip + stride);   // request the next strip, then write this one out
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = m_lane + mt * 16;
+                if (m >= a.M) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n0 = n_blk + nb * 64 + i * 16 + ((l >> 4) << 2);
+                    if (n0 >= a.N) continue;
+                    epi_quad<T>(a, acc[i][mt], m, n0, rs[mt], 0);
                 }
             }
         }
     }
+}
+
+template <typename T, int NCH, bool WT>
+int launch_stream(const GemmArgs& a, hipStream_t st) {
+    constexpr int RL = NCH * 64;
+    const int maxb = ((64 * 1024) / RL) & ~63;                      // panel columns that fit 64 KB (2 workgroups per CU)
+    const int ny = fw_cdiv(a.N, maxb);
+    const int bnp = fw_cdiv(fw_cdiv(a.N, ny), 64) * 64;
+    const size_t lds = (size_t)bnp * RL;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<T, NCH, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_done = true;
+    }
+    const int strips = fw_cdiv(a.M, 32);
+    int gx = fw_cdiv(strips, 8);
+    const int cap = 512 / ny > 0 ? 512 / ny : 1;                    // 256 CUs x 2 workgroups
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL((gemm_stream_kernel<T, NCH, WT>), dim3(gx, ny), dim3(512), lds, st, a, bnp);
+    FW_LAUNCH_RET();
+}
+
+template <typename T>
+int dispatch_stream(const GemmArgs& a, int wt, hipStream_t st) {
+    const int nch = fw_cdiv(a.K * TT<T>::SZ, 128) * 2;
+    if (nch <= 2) return wt ? launch_stream<T, 2, true>(a, st) : launch_stream<T, 2, false>(a, st);
+    if (nch <= 4) return wt ? launch_stream<T, 4, true>(a, st) : launch_stream<T, 4, false>(a, st);
+    return wt ? launch_stream<T, 8, true>(a, st) : launch_stream<T, 8, false>(a, st);
 }
 
 template <typename T, int BN, bool XT, bool WT, bool GX, bool GW>
@@ -452,6 +587,11 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
     a.kper = fw_cdiv(fw_cdiv(K, kt), splitk) * kt;
     a.alpha = alpha;
     hipStream_t st = (hipStream_t)stream;
+    // tall-skinny products stream X past a W panel held in LDS (gemm_stream_kernel)
+    static const long stream_min_m = getenv("FW_GEMM_STREAM_MIN_M") ? atol(getenv("FW_GEMM_STREAM_MIN_M")) : 32768;
+    if (!x_trans && splitk == 1 && !accumulate && x_op == 0 && w_op == 0 && !xsum && K * sz <= 512 && M >= stream_min_m) {
+        return dtype == FW_DT_BF16 ? dispatch_stream<bf16raw>(a, w_trans, st) : dispatch_stream<float>(a, w_trans, st);
+    }
     // 128x64 tiles when N is narrow or when 128x128 tiles would leave most of the 256 CUs (2 blocks each) idle
     const bool small_n = N <= 64 || (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk < 384;
     if (dtype == FW_DT_BF16) {

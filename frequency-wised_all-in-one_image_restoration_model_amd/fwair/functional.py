@@ -182,7 +182,7 @@ class LinearFn(torch.autograd.Function):
         dx = dpre = None
         if ctx.needs_input_grad[0] or (x_pre is not None and ctx.needs_input_grad[6]):
             d = act_empty(M, K, x.dtype, x.device)
-            ops.gemm(g, shadow(weight), M, K, N, w_trans=True, out=d, act=2 if x_pre is not None else 0, aux=x_pre)
+            ops.dgrad(g, shadow(weight), M, K, N, d, act=2 if x_pre is not None else 0, aux=x_pre)
             if x_pre is not None:
                 dpre = d
             else:

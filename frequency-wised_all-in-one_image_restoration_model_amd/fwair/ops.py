@@ -58,6 +58,24 @@ def wgrad(g, x, n, k, m, dw, db=None):
     call('fw_slab_reduce', slab, sk, n * k, S, dw, 1, db, nk, n if db is not None else 0)
 
 
+def dgrad(g, w, M, K, N, out, act=0, aux=None):
+    """out[M,K] = epi(g[M,N] W[N,K])  (input gradient of a Linear).  A long reduction into a small output -- the 65536-wide
+    mlp_head of the encoder: 32 output tiles, 1024 K-steps each -- is split over N into a slab of partial tiles."""
+    tiles = ((M + 127) // 128) * ((K + 127) // 128)
+    sk = min(512 // max(tiles, 1), N // 2048) if act == 0 else 1
+    if sk <= 1:
+        gemm(g, w, M, K, N, w_trans=True, out=out, act=act, aux=aux)
+        return
+    S = (M * K + 3) // 4 * 4
+    slab = torch.empty((sk, S), dtype=torch.float32, device=g.device)
+    gemm(g, w, M, K, N, w_trans=True, out=slab[0, :M * K].view(M, K), splitk=sk, c_zstride=S)
+    direct = out.dtype == torch.float32 and out.is_contiguous()
+    tmp = out if direct else torch.empty((M, K), dtype=torch.float32, device=g.device)
+    call('fw_slab_reduce', slab, sk, M * K, S, tmp, 0, None, 0, 0)
+    if not direct:
+        call('fw_cast_rows', dt(out.dtype), tmp, K, out, _ld(out), M, K, None, 1)
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm
 def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
     rows, C = x.shape

@@ -129,6 +129,57 @@ def test_gemm_tn_dw(dtype, M, N, K, split):
     close(db - 1, dy.sum(0), 1e-4, 'wgrad bias')
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,N,K', [(32768 + 45, 224, 56), (33000, 56, 28), (32800, 448, 112), (32768, 132, 224), (40000, 672, 224),
+                                   (32790, 28, 112)])
+def test_gemm_stream_tall_skinny(dtype, M, N, K):
+    """M >= 32768 with K*sizeof(T) <= 512 takes gemm_stream_kernel (W panel in LDS, X fragments straight from HBM):
+    NT and NN forms, ragged last strip, N not a multiple of 64, K tails, every epilogue, several column panels."""
+    if dtype == torch.float32 and K > 128:
+        K = 128 - 4                                         # f32: 512 bytes of K at most on this path
+    x, w = q(rnd(M, K), dtype), q(rnd(N, K, seed=1) * 0.1, dtype)
+    ldk, ldn = (K + 7) // 8 * 8, (N + 7) // 8 * 8
+    xp = torch.full((M, ldk), float('nan')); xp[:, :K] = x
+    wp = torch.full((N, ldk), float('nan')); wp[:, :K] = w
+    xd, wd = xp.to(DEV, dtype)[:, :K], wp.to(DEV, dtype)[:, :K]
+    bias, res = rnd(N, seed=2), rnd(M, N, seed=3)
+    rows_per = 4096
+    rs = torch.rand((M + rows_per - 1) // rows_per) + 0.5
+    ref = F.linear(x.double(), w.double())
+    y = ops().gemm(xd, wd, M, N, K, bias=bias.to(DEV))
+    close(y, ref + bias.double(), TOL[dtype], 'stream NT bias')
+    y = ops().gemm(xd, wd, M, N, K, bias=bias.to(DEV), rowscale=rs.to(DEV), rows_per_scale=rows_per, residual=res.to(DEV),
+                   out_dtype=torch.float32)
+    close(y, res.double() + (ref + bias.double()) * rs.double().repeat_interleave(rows_per)[:M, None], TOL[dtype], 'stream NT rowscale+residual')
+    aux = q(rnd(M, N, seed=5), dtype)
+    y = ops().gemm(xd, wd, M, N, K, act=2, aux=aux.to(DEV, dtype), out_dtype=torch.float32)
+    a64 = aux.double()
+    gp = 0.5 * (1 + torch.erf(a64 / math.sqrt(2))) + a64 * torch.exp(-0.5 * a64 * a64) / math.sqrt(2 * math.pi)
+    close(y, ref * gp, TOL[dtype], 'stream NT gelu-grad epilogue')
+    g = torch.full((M, ldn), 7.0, device=DEV, dtype=dtype)
+    y = ops().gemm(xd, wd, M, N, K, bias=bias.to(DEV), out_gelu=g[:, :N])
+    close(g[:, :N], F.gelu(ref + bias.double()), TOL[dtype], 'stream NT second output')
+    if ldn > N:
+        assert float((g[:, N:].float() - 7.0).abs().max()) == 0.0, 'padding columns were written'
+    # NN: dX[M,N] = dY[M,K] W[K,N]
+    w2 = q(rnd(K, N, seed=6) * 0.1, dtype)
+    w2p = torch.full((K, ldn), float('nan')); w2p[:, :N] = w2
+    y = ops().gemm(xd, w2p.to(DEV, dtype)[:, :N], M, N, K, w_trans=True, out_dtype=torch.float32)
+    close(y, x.double() @ w2.double(), TOL[dtype], 'stream NN')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_dgrad_split_reduction(dtype):
+    """Input gradient of the 65536-wide mlp_head (encoder_Uformer.py:942): small output, very long reduction -> split
+    over N into partial tiles + slab reduce (ops.dgrad)."""
+    M, K, N = 256, 448, 16384
+    g, w = q(rnd(M, N), dtype), q(rnd(N, K, seed=1) * 0.05, dtype)
+    out = torch.full((M, K + 8), 3.0, device=DEV, dtype=dtype)
+    ops().dgrad(g.to(DEV, dtype), w.to(DEV, dtype), M, K, N, out[:, :K])
+    close(out[:, :K], g.double() @ w.double(), TOL[dtype], 'split dgrad')
+    assert float((out[:, K:].float() - 3.0).abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('rows,C', [(1000, 28), (777, 56), (512, 112), (300, 448), (130, 896)])

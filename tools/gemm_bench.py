@@ -34,6 +34,9 @@ def report(tag, M, N, K, t, bytes_):
 stages = [(262144, 56), (65536, 112), (16384, 224), (4096, 448), (1024, 896), (4096, 896), (16384, 448), (65536, 224), (262144, 112),
           (786432, 28), (196608, 56), (49152, 112), (12288, 224), (3072, 448)]
 tot = {'NT': 0.0, 'NN': 0.0, 'TN': 0.0}
+skinny = len(sys.argv) > 2 and sys.argv[2] == 'skinny'          # only the shapes of gemm_stream_kernel, no weight grads
+if skinny:
+    stages = [s for s in stages if s[0] >= 32768]
 for T, C in stages:
     for (N, K) in ((C, C), (2 * C, C), (4 * C, C), (C, 4 * C)):
         ldk = (K + 7) // 8 * 8
@@ -49,6 +52,8 @@ for T, C in stages:
         t = timeit(lambda: ops.gemm(g, w, T, K, N, w_trans=True, out=dx))
         report(f'NN  dx=gW C={C}', T, K, N, t, (T * K + N * K + T * N) * sz)
         tot['NN'] += t
+        if skinny:
+            continue
         dw = torch.zeros(N, K, device=dev)
         sk = ops.pick_splitk(N, K, T, dtype)
         db = torch.zeros(N, device=dev)

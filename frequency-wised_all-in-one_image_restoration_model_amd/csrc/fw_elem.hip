@@ -89,7 +89,7 @@ constexpr int SX = 8;     // strip length (W is a multiple of 8 everywhere in th
 
 // MODE 0: forward (writes out = conv + bias and out2 = GELU(out));  MODE 1: data gradient (flipped taps, times GELU'(pre))
 template <typename T, int MODE>
-__global__ void dwconv_strip_kernel(const T* __restrict__ in, long ldi, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__ in, long ldi, const float* __restrict__ w, const float* __restrict__ bias,
                                     const T* __restrict__ pre, T* __restrict__ out, T* __restrict__ out2, long ldo, int B, int H, int W, int C) {
     constexpr int E = TT<T>::E16;
     const int nv = C / E, ns = W / SX;
@@ -564,14 +564,33 @@ __global__ void lrelu_bwd_kernel(const T* __restrict__ dy, const float* __restri
 }
 // dst[i] (+)= sum_z slab[z*zstride + i]: the reduction step of a split-K GEMM (replaces thousands of same-address atomics).
 // Two destination segments in one launch: [0, n) -> dst, [off2, off2 + n2) -> dst2 (weight and bias gradient of one GEMM).
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long n, long zstride, float* __restrict__ dst, int accumulate, int zper,
-                                   float* __restrict__ dst2, long off2, long n2) {
-    const long i4 = gtid();
+// One wave = 64 consecutive 16-byte columns (1 KB per slab row); the 4 waves of a block take every 4th slab row of the
+// block's z range (independent, unrolled loads), are folded through LDS, and wave 0 writes the result.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nz, long n, long zstride, float* __restrict__ dst,
+                                                          int accumulate, int zper, float* __restrict__ dst2, long off2, long n2) {
+    __shared__ f32x4 red[3][64];
+    const int lane = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const long i4 = (long)blockIdx.x * 64 + lane;
     const long end = dst2 ? off2 + n2 : n;
-    if (i4 * 4 >= end) return;
+    const bool live = i4 * 4 < end;
     const int z0 = blockIdx.y * zper, z1 = min(nz, z0 + zper);
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int z = z0; z < z1; ++z) s += *reinterpret_cast<const f32x4*>(slab + (long)z * zstride + i4 * 4);   // rows are padded to 4
+    if (live) {
+        const float* p = slab + i4 * 4;
+        int z = z0 + zl;
+        for (; z + 12 < z1; z += 16) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (long)z * zstride);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + (long)(z + 4) * zstride);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (long)(z + 8) * zstride);
+            const f32x4 a3 = *reinterpret_cast<const f32x4*>(p + (long)(z + 12) * zstride);
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; z < z1; z += 4) s += *reinterpret_cast<const f32x4*>(p + (long)z * zstride);   // rows are padded to 4
+    }
+    if (zl > 0) red[zl - 1][lane] = s;
+    __syncthreads();
+    if (zl > 0 || !live) return;
+    s += red[0][lane] + red[1][lane] + red[2][lane];
     for (int e = 0; e < 4; ++e) {
         const long i = i4 * 4 + e;
         float* d = nullptr;
@@ -760,17 +779,23 @@ extern "C" int fw_lrelu_bwd(int dtype, const void* dy, const float* x, float* dx
     if (dtype == FW_DT_BF16) LAUNCH((lrelu_bwd_kernel<bf16raw>), n, (const bf16raw*)dy, x, dx, n, slope);
     LAUNCH((lrelu_bwd_kernel<float>), n, (const float*)dy, x, dx, n, slope);
 }
-// dst must be pre-initialised when accumulate != 0 or when nz > 64 (the z range is then split over blockIdx.y with atomics).
+// dst must be pre-initialised when accumulate != 0 (the z range may then be split over blockIdx.y with atomics).
 // zstride and the segment [0, max(n, off2 + n2)) rounded up to 4 must lie inside every slab row.
 extern "C" int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, float* dst2, long off2, long n2,
                               void* stream) {
     FW_CHECK_ARG(slab && dst && nz > 0 && n > 0 && zstride % 4 == 0 && ((uintptr_t)slab & 15) == 0);
-    FW_CHECK_ARG(accumulate || nz <= 64);
     FW_CHECK_ARG(!dst2 || (off2 >= n && n2 > 0 && off2 + n2 <= zstride));
-    const int zper = 64;
     const long end = dst2 ? off2 + n2 : n;
-    dim3 grid((unsigned)(((end + 3) / 4 + TPB - 1) / TPB), (unsigned)((nz + zper - 1) / zper));
-    hipLaunchKernelGGL(slab_reduce_kernel, grid, dim3(TPB), 0, ST, slab, nz, n, zstride, dst, accumulate, zper, dst2, off2, n2);
+    const long gx = ((end + 3) / 4 + 63) / 64;
+    int zper = nz;                                  // plain stores need the whole z range in one block
+    if (accumulate) {                               // aim at >= ~1024 blocks, at least 8 slab rows per block
+        long splits = 1024 / gx;
+        if (splits > nz / 8) splits = nz / 8;
+        if (splits < 1) splits = 1;
+        zper = (int)((nz + splits - 1) / splits);
+    }
+    dim3 grid((unsigned)gx, (unsigned)((nz + zper - 1) / zper));
+    hipLaunchKernelGGL(slab_reduce_kernel, grid, dim3(256), 0, ST, slab, nz, n, zstride, dst, accumulate, zper, dst2, off2, n2);
     FW_LAUNCH_RET();
 }
 extern "C" int fw_fill(float* p, long n, float v, void* stream) {

@@ -148,6 +148,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, rowscale, rows_per_scale, x_pre, gelu_out, out_f32):
+        ctx.set_materialize_grads(False)            # the GELU twin never gets a gradient: do not zero-fill one for it
         M, K = x.shape
         N = weight.shape[0]
         w = shadow(weight)
@@ -168,6 +169,8 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *_):
+        if dy is None:
+            return (None,) * 9
         x, weight, rowscale, x_pre = ctx.saved_tensors
         rows_per_scale, has_res = ctx.cfg
         bias = ctx.bias
@@ -196,6 +199,7 @@ class LnResFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta):
+        ctx.set_materialize_grads(False)
         rows, C = x.shape
         y = act_empty(rows, C, config.compute_dtype, x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -257,10 +261,14 @@ class QKVFn(torch.autograd.Function):
 # window attention
 # ---------------------------------------------------------------------------------------------------------------
 class WindowAttnFn(torch.autograd.Function):
-    """qkv: buffer of QKVFn.  tables: f32 [ntab, 225, heads].  coef: f32 [B, heads, 3] or None."""
+    """qkv: buffer of QKVFn.  tables: f32 [ntab, 225, heads].  coef: f32 [B, heads, 3] or None.
+    tparam: the Parameter `tables` is a view of (engine mode: its flat .grad view takes the kernel's atomics directly).
+    dcoef_to: f32 [B, heads, 3] slice of the coefficient producer's gradient buffer -- the kernel accumulates there and
+    autograd gets None (a slice gradient would cost a full-size zero-fill + add per block)."""
 
     @staticmethod
-    def forward(ctx, qkv, tables, coef, geo):
+    def forward(ctx, qkv, tables, coef, geo, tparam, dcoef_to):
+        ctx.side = (tparam, dcoef_to)
         C, B, H, W, heads, L, mode, shift, lfs = geo
         D = C // heads
         Cp = (C + 7) // 8 * 8
@@ -286,8 +294,17 @@ class WindowAttnFn(torch.autograd.Function):
         dout = aligned(dout)
         dqkv = act_empty(rows, qkv.shape[1], qkv.dtype, qkv.device)
         d2 = act_empty(rows, qkv.shape[1], qkv.dtype, qkv.device) if nkt == 2 else None
-        dtab = _zeros(tables.shape, qkv.device)
-        dcoef = _zeros(coef.shape, qkv.device) if coef is not None else None
+        tparam, dcoef_to = ctx.side
+        if config.direct_grads and tparam is not None and tparam.grad is not None:
+            dtab, rtab = tparam.grad.view(tables.shape), None
+        else:
+            dtab = rtab = _zeros(tables.shape, qkv.device)
+        if coef is None:
+            dcoef = rcoef = None
+        elif dcoef_to is not None:
+            dcoef, rcoef = dcoef_to, None
+        else:
+            dcoef = rcoef = _zeros(coef.shape, qkv.device)
         tab = ops._lfs.device_table(qkv.dtype, qkv.device) if lfs == 2 else None
         call('fw_attn_bwd', dt(qkv.dtype), D, nkt, lfs, qkv, qkv[:, Cp:], qkv[:, Cp + C:], qkv.stride(0), out, out.stride(0),
              dout, dout.stride(0), lse, tables, coef, tab, dqkv, dqkv[:, Cp:], dqkv[:, Cp + C:],
@@ -295,7 +312,7 @@ class WindowAttnFn(torch.autograd.Function):
              B, H, W, heads, L, mode, shift, float(D) ** -0.5)
         if nkt == 2:
             call('fw_add_rows', dt(qkv.dtype), d2[:, Cp:], d2.stride(0), dqkv[:, Cp:], dqkv.stride(0), rows, 2 * C)
-        return dqkv, dtab, dcoef, None
+        return dqkv, rtab, rcoef, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -307,6 +324,7 @@ class DwConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h1, g1, weight, bias, B, H, W):
+        ctx.set_materialize_grads(False)
         C = h1.shape[1]
         h2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
         g2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
@@ -321,6 +339,8 @@ class DwConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dh2, _):
+        if dh2 is None:
+            return (None,) * 7
         h1, g1, weight, wt = ctx.saved_tensors
         B, H, W = ctx.geo
         C = h1.shape[1]
@@ -570,6 +590,7 @@ class LfsLambdaFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, inter, meta, *params):
+        ctx.set_materialize_grads(False)
         heads_list, B, nb1 = meta
         dev = inter.device
         C = inter.shape[1]
@@ -610,10 +631,15 @@ class LfsLambdaFn(torch.autograd.Function):
         ctx.save_for_backward(inter, xbar, stats, ptab, heads, coef_off, save, *params)
         ctx.meta = meta
         ctx.gbuf = (gflat, gt)
+        ctx.dcoef = torch.zeros_like(coef)          # the attention kernels of all blocks accumulate here (WindowAttnFn dcoef_to)
         return coef
 
     @staticmethod
     def backward(ctx, dcoef):
+        if dcoef is None:
+            dcoef = ctx.dcoef
+        else:
+            dcoef = dcoef + ctx.dcoef
         inter, xbar, stats, ptab, heads, coef_off, save = ctx.saved_tensors[:7]
         params = ctx.saved_tensors[7:]
         heads_list, B, nb1 = ctx.meta
@@ -663,10 +689,48 @@ def set_droppath_override(fn):
     _dp_override = fn
 
 
+class _DropPathPool:
+    """All DropPath row scales of one training step from ONE draw.  The calls of a step come in a fixed order; the first step
+    records (samples, keep) of every call while drawing one by one, later steps draw a single vector at droppath_begin()
+    and hand out slices -- 3 tiny kernels per step instead of 5 per block."""
+
+    def __init__(self):
+        self.plan, self.keep_vec, self.cursor, self.offset, self.pool, self.recording = [], None, 0, 0, None, True
+
+    def begin(self, device):
+        if self.recording and self.plan and self.cursor == len(self.plan):
+            self.keep_vec = torch.cat([torch.full((n,), k, dtype=torch.float32) for n, k in self.plan]).to(device)
+            self.recording = False
+        self.cursor = self.offset = 0
+        if not self.recording:
+            self.pool = torch.floor(self.keep_vec + torch.rand(self.keep_vec.numel(), device=device)) / self.keep_vec
+        elif self.plan:
+            self.plan = []                                   # an incomplete first pass (e.g. an eval forward in between): record again
+
+    def draw(self, nsamples, keep, device):
+        if not self.recording:
+            i = self.cursor
+            if i < len(self.plan) and self.plan[i] == (nsamples, keep):
+                out = self.pool[self.offset:self.offset + nsamples]
+                self.cursor, self.offset = i + 1, self.offset + nsamples
+                return out
+            self.__init__()                                  # the model or batch changed: fall back and record anew
+        self.plan.append((nsamples, keep))
+        self.cursor = len(self.plan)
+        return torch.floor(keep + torch.rand(nsamples, device=device)) / keep
+
+
+_dp_pool = _DropPathPool()
+
+
+def droppath_begin(device):
+    """Call once at the start of every training forward (net.model.AirNet.forward does)."""
+    _dp_pool.begin(device)
+
+
 def droppath_scale(name, nsamples, rate, training, device):
     if not training or rate == 0.0:
         return None
     if _dp_override is not None:
         return _dp_override(name, nsamples, rate, device)
-    keep = 1.0 - rate
-    return torch.floor(keep + torch.rand(nsamples, device=device)) / keep
+    return _dp_pool.draw(nsamples, 1.0 - rate, device)

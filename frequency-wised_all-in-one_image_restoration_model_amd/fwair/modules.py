@@ -205,7 +205,8 @@ class DecLeWinTransformerBlock(nn.Module):
         x, xn = Fn.LnResFn.apply(x, self.norm1.weight, self.norm1.bias)
         qkv = self.attn.qkv(xn)
         geo = (C, batch, h, h, self.num_heads, 1, 0, self.shift_size, self.attn.lfs_mode if coef is not None else 0)
-        o = Fn.WindowAttnFn.apply(qkv, self.attn.relative_position_bias_table.unsqueeze(0), coef, geo)
+        tab = self.attn.relative_position_bias_table
+        o = Fn.WindowAttnFn.apply(qkv, tab.unsqueeze(0), coef, geo, tab, getattr(coef, '_fw_dgrad', None))
         x = Fn.linear(o, self.attn.proj.weight, self.attn.proj.bias, residual=x, rowscale=dp, rows_per_scale=h * h)
         x, xn2 = Fn.LnResFn.apply(x, self.norm2.weight, self.norm2.bias)
         return self.mlp.run(xn2, x, dp, batch)
@@ -297,8 +298,12 @@ class UformerDecoder(nn.Module):
         heads = tuple(blk.num_heads for blk in blocks)
         coef = Fn.LfsLambdaFn.apply(bands, (heads, B, nb - 1), *params)
         out, o = [], 0
+        dgrad = getattr(coef.grad_fn, 'dcoef', None) if coef.grad_fn is not None else None     # LfsLambdaFn's accumulation buffer
         for h in heads:
-            out.append(coef[o:o + B * h * 3].view(B, h, 3))
+            c = coef[o:o + B * h * 3].view(B, h, 3)
+            if dgrad is not None:
+                c._fw_dgrad = dgrad[o:o + B * h * 3].view(B, h, 3)
+            out.append(c)
             o += B * h * 3
         return out
 
@@ -409,15 +414,15 @@ class EncLeWinTransformerBlock(nn.Module):
         x, xn = Fn.LnResFn.apply(x, self.norm1.weight, self.norm1.bias)
         if self.encoder_msa_type == 'origin':
             geo = (C, nimg, h, h, self.num_heads, 1, 0, self.shift_size, 0)
-            o = Fn.WindowAttnFn.apply(self.attn.qkv(xn), self.attn.tables(), None, geo)
+            o = Fn.WindowAttnFn.apply(self.attn.qkv(xn), self.attn.tables(), None, geo, None, None)
             x = Fn.linear(o, self.attn.proj.weight, self.attn.proj.bias, residual=x, rowscale=dp, rows_per_scale=h * h)
         else:
             B = nimg // self.L
             a = self.attn_intra
-            o = Fn.WindowAttnFn.apply(a.qkv(xn), a.tables(), None, (C, B, h, h, self.num_heads, self.L, 0, self.shift_size, 0))
+            o = Fn.WindowAttnFn.apply(a.qkv(xn), a.tables(), None, (C, B, h, h, self.num_heads, self.L, 0, self.shift_size, 0), None, None)
             y1 = Fn.linear(o, a.proj.weight, a.proj.bias)
             a = self.attn_inter
-            o = Fn.WindowAttnFn.apply(a.qkv(y1), a.tables(), None, (C, B, h, h, self.num_heads, self.L, 1, self.shift_size, 0))
+            o = Fn.WindowAttnFn.apply(a.qkv(y1), a.tables(), None, (C, B, h, h, self.num_heads, self.L, 1, self.shift_size, 0), None, None)
             x = Fn.linear(o, a.proj.weight, a.proj.bias, residual=x, rowscale=dp, rows_per_scale=h * h)
         x, xn2 = Fn.LnResFn.apply(x, self.norm2.weight, self.norm2.bias)
         return self.mlp.run(xn2, x, dp, nimg)

@@ -69,6 +69,7 @@ class AirNet(nn.Module):
     def forward(self, x_query, x_key):
         _apply_dtype(self.opt)
         if self.training:
+            _Fn.droppath_begin(x_query.device)
             fea, logits, labels, inter = self.E(x_query, x_key)
             restored = self.R(x_query, inter)
             return restored, logits, labels

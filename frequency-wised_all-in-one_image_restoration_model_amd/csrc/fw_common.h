@@ -74,7 +74,7 @@ template <> FW_SPEC uint4 pack16<bf16raw>(const float* f) {
 // libm's erff is a multi-branch polynomial several times that long, and GELU / GELU' run on every hidden element.
 FW_DEV float erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);   // v_rcp_f32 (1 ulp), not the 10-instruction IEEE division
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float r = 1.0f - poly * __expf(-ax * ax);
     return copysignf(r, x);

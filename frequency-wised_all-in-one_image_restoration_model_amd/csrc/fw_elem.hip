@@ -94,7 +94,10 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
     constexpr int E = TT<T>::E16;
     const int nv = C / E, ns = W / SX;
     const long total = (long)B * H * ns * nv;
-    for (long i = gtid(); i < total; i += gstride()) {
+    // workgroups are dealt round-robin to the 8 XCDs (8 private L2s): give every XCD one CONTIGUOUS eighth of the rows, so
+    // that the three output rows sharing an input row meet it in the same L2 instead of fetching it on three XCDs
+    const long lb = (gridDim.x % 8 == 0) ? (long)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (long)blockIdx.x;
+    for (long i = lb * TPB + threadIdx.x; i < total; i += gstride()) {
         const int v = (int)(i % nv); long t = i / nv;
         const int sx = (int)(t % ns); t /= ns;
         const int y = (int)(t % H); const long b = t / H;
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
         const int k = i % 10, ce = i / 10;
         const int c = (blockIdx.x % nvg) * 8 * E + ce;
         if (c < C) {
-            if (k < 9) atomicAdd(dw + (long)k * C + c, red[i]);                       // tap-major, like the weights
+            if (k < 9) atomicAdd(dw + (long)c * 9 + k, red[i]);                       // the parameter's own [C][3][3] layout
             else atomicAdd(dbias + c, red[i]);
         }
     }
@@ -602,6 +605,54 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
         else *d = s[e];
     }
 }
+// Many slabs in one launch (every weight-gradient / LayerNorm partial of a backward pass, folded once at its end).
+// tab: [num][10] int64 = slab, dst, dst2, n, zstride, off2, n2, nz, zper, gx;  prefix: [num + 1] int64 block offsets.
+// Every entry accumulates into dst / dst2 (atomics when its z range is split over several blocks).
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const long long* __restrict__ tab, const long long* __restrict__ prefix, int num) {
+    __shared__ f32x4 red[3][64];
+    int lo = 0, hi = num;                                  // entry e with prefix[e] <= blockIdx.x < prefix[e + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= (long long)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const long long* t = tab + (long)lo * 10;
+    const float* slab = reinterpret_cast<const float*>(t[0]);
+    float* dst = reinterpret_cast<float*>(t[1]);
+    float* dst2 = reinterpret_cast<float*>(t[2]);
+    const long n = t[3], zstride = t[4], off2 = t[5], n2 = t[6];
+    const int nz = (int)t[7], zper = (int)t[8], gx = (int)t[9];
+    const int local = (int)((long long)blockIdx.x - prefix[lo]);
+    const int bx = local % gx, by = local / gx;
+    const int lane = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const long i4 = (long)bx * 64 + lane;
+    const long end = dst2 ? off2 + n2 : n;
+    const bool live = i4 * 4 < end;
+    const int z0 = by * zper, z1 = min(nz, z0 + zper);
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float* p = slab + i4 * 4;
+        int z = z0 + zl;
+        for (; z + 12 < z1; z += 16) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (long)z * zstride);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + (long)(z + 4) * zstride);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (long)(z + 8) * zstride);
+            const f32x4 a3 = *reinterpret_cast<const f32x4*>(p + (long)(z + 12) * zstride);
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; z < z1; z += 4) s += *reinterpret_cast<const f32x4*>(p + (long)z * zstride);
+    }
+    if (zl > 0) red[zl - 1][lane] = s;
+    __syncthreads();
+    if (zl > 0 || !live) return;
+    s += red[0][lane] + red[1][lane] + red[2][lane];
+    for (int e = 0; e < 4; ++e) {
+        const long i = i4 * 4 + e;
+        float* d = nullptr;
+        if (i < n) d = dst + i;
+        else if (dst2 && i >= off2 && i < off2 + n2) d = dst2 + (i - off2);
+        if (d) atomicAdd(d, s[e]);       // always atomic: z-split entries, and two entries may share a destination (a weight used twice)
+    }
+}
 __global__ void fill_kernel(float* __restrict__ p, long n, float v) {
     for (long i = gtid(); i < n; i += gstride()) p[i] = v;
 }
@@ -651,9 +702,14 @@ extern "C" int fw_dwconv_fwd(int dtype, const void* g1, long ld1, const float* w
     const int e = dtype == FW_DT_BF16 ? 8 : 4;
     FW_CHECK_ARG(g1 && w && bias && h2 && g2 && C % e == 0 && ld1 % e == 0 && ld2 % e == 0 && W % SX == 0);
     const long n = (long)B * H * (W / SX) * (C / e);
+    const dim3 grid((unsigned)((grid_for(n) + 7) / 8 * 8));            // multiple of 8: XCD-contiguous block mapping
     if (dtype == FW_DT_BF16)
-        LAUNCH((dwconv_strip_kernel<bf16raw, 0>), n, (const bf16raw*)g1, ld1, w, bias, (const bf16raw*)nullptr, (bf16raw*)h2, (bf16raw*)g2, ld2, B, H, W, C);
-    LAUNCH((dwconv_strip_kernel<float, 0>), n, (const float*)g1, ld1, w, bias, (const float*)nullptr, (float*)h2, (float*)g2, ld2, B, H, W, C);
+        hipLaunchKernelGGL((dwconv_strip_kernel<bf16raw, 0>), grid, dim3(TPB), 0, ST, (const bf16raw*)g1, ld1, w, bias, (const bf16raw*)nullptr,
+                           (bf16raw*)h2, (bf16raw*)g2, ld2, B, H, W, C);
+    else
+        hipLaunchKernelGGL((dwconv_strip_kernel<float, 0>), grid, dim3(TPB), 0, ST, (const float*)g1, ld1, w, bias, (const float*)nullptr,
+                           (float*)h2, (float*)g2, ld2, B, H, W, C);
+    FW_LAUNCH_RET();
 }
 extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g1, const void* h1, long ld1, const float* w, void* dh1,
                              long ldo, float* dw, float* dbias, int B, int H, int W, int C, void* stream) {
@@ -667,11 +723,11 @@ extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g
     const long nsg = (((long)B * H * (W / SX) + NSTRIP - 1) / NSTRIP + 31) / 32;
     const dim3 gridw((unsigned)(nsg * nvg));
     if (dtype == FW_DT_BF16) {
-        hipLaunchKernelGGL((dwconv_strip_kernel<bf16raw, 1>), dim3(grid_for(n)), dim3(TPB), 0, ST, (const bf16raw*)dh2, ldg, w, (const float*)nullptr,
+        hipLaunchKernelGGL((dwconv_strip_kernel<bf16raw, 1>), dim3((grid_for(n) + 7) / 8 * 8), dim3(TPB), 0, ST, (const bf16raw*)dh2, ldg, w, (const float*)nullptr,
                            (const bf16raw*)h1, (bf16raw*)dh1, (bf16raw*)nullptr, ldo, B, H, W, C);
         hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16raw>), gridw, dim3(256), 0, ST, (const bf16raw*)dh2, ldg, (const bf16raw*)g1, ld1, dw, dbias, B, H, W, C, NSTRIP);
     } else {
-        hipLaunchKernelGGL((dwconv_strip_kernel<float, 1>), dim3(grid_for(n)), dim3(TPB), 0, ST, (const float*)dh2, ldg, w, (const float*)nullptr,
+        hipLaunchKernelGGL((dwconv_strip_kernel<float, 1>), dim3((grid_for(n) + 7) / 8 * 8), dim3(TPB), 0, ST, (const float*)dh2, ldg, w, (const float*)nullptr,
                            (const float*)h1, (float*)dh1, (float*)nullptr, ldo, B, H, W, C);
         hipLaunchKernelGGL((dwconv_wgrad_kernel<float>), gridw, dim3(256), 0, ST, (const float*)dh2, ldg, (const float*)g1, ld1, dw, dbias, B, H, W, C, NSTRIP);
     }
@@ -796,6 +852,13 @@ extern "C" int fw_slab_reduce(const float* slab, int nz, long n, long zstride, f
     }
     dim3 grid((unsigned)gx, (unsigned)((nz + zper - 1) / zper));
     hipLaunchKernelGGL(slab_reduce_kernel, grid, dim3(256), 0, ST, slab, nz, n, zstride, dst, accumulate, zper, dst2, off2, n2);
+    FW_LAUNCH_RET();
+}
+// One launch for `num` slabs.  tab / prefix are DEVICE arrays laid out as slab_reduce_multi_kernel documents (the host picks
+// zper and gx = ceil(ceil(max(n, off2 + n2) / 4) / 64) per entry; an entry owns gx * ceil(nz / zper) consecutive blocks).
+extern "C" int fw_slab_reduce_multi(const void* tab, const void* prefix, int num, long total_blocks, void* stream) {
+    FW_CHECK_ARG(tab && prefix && num > 0 && total_blocks > 0 && total_blocks < (1L << 31));
+    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, ST, (const long long*)tab, (const long long*)prefix, num);
     FW_LAUNCH_RET();
 }
 extern "C" int fw_fill(float* p, long n, float v, void* stream) {

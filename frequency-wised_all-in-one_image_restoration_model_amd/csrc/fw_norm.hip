@@ -203,15 +203,15 @@ extern "C" int fw_layernorm_fwd(int dtype, const float* x, long ldx, const float
 // Number of block partials fw_layernorm_bwd writes for (rows, C): the caller provides `partial` f32 [blocks][2 * roundup(C, 4)].
 extern "C" int fw_layernorm_bwd_blocks(int rows, int C) { return ln_bwd_grid(rows, C); }
 
-// dx = (dres?) + LN'(dy).  The per-block column sums of dy*xhat / dy go to `partial` (plain stores) and are folded into
-// dgamma / dbeta (accumulated) by fw_slab_reduce, launched here on the same stream.
+// dx = (dres?) + LN'(dy).  The per-block column sums of dy*xhat / dy go to `partial` (plain stores, row = [dgamma | dbeta]) and
+// are folded into dgamma / dbeta (accumulated) by fw_slab_reduce, launched here on the same stream -- unless both are null.
 extern "C" int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, float* dst2, long off2, long n2,
                               void* stream);
 extern "C" int fw_layernorm_bwd(int dtype, const void* dy, long lddy, const float* x, long ldx, const float* gamma,
                                 const float* mean, const float* rstd, const float* dres, long lddres, float* dx,
                                 long lddx, float* dgamma, float* dbeta, float* partial, int rows, int C, void* stream) {
     FW_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0);
-    FW_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && partial);
+    FW_CHECK_ARG(dy && x && gamma && mean && rstd && dx && partial && ((dgamma && dbeta) || (!dgamma && !dbeta)));
     hipStream_t st = (hipStream_t)stream;
     const long pstride = 2L * C;
 #define LN_B(T)                                                                                                      \
@@ -223,6 +223,6 @@ extern "C" int fw_layernorm_bwd(int dtype, const void* dy, long lddy, const floa
                                                pstride, rows, C, st))
     const int rc = dtype == FW_DT_BF16 ? LN_B(bf16raw) : LN_B(float);
 #undef LN_B
-    if (rc) return rc;
+    if (rc || !dgamma) return rc;                  // dgamma == dbeta == null: the caller folds the partials later (fw_slab_reduce_multi)
     return fw_slab_reduce(partial, ln_bwd_grid(rows, C), C, pstride, dgamma, 1, dbeta, C, C, stream);
 }

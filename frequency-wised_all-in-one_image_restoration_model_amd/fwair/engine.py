@@ -15,6 +15,7 @@ import torch
 import torch.distributed as dist
 
 from . import functional as Fn
+from . import ops
 from .lib import call
 
 
@@ -63,6 +64,25 @@ def _layout(params):
         offs.append(o)
         o += (p.numel() + 7) // 8 * 8
     return offs, o
+
+
+def ordered_parameters(root):
+    """root.parameters() with each LinearProjection's tensors regrouped as (to_q.weight, to_kv.weight, to_q.bias, to_kv.bias):
+    adjacent in a flat buffer they form one [3C, C] weight and one [3C] bias."""
+    from .modules import LinearProjection
+    group = {}
+    for mod in root.modules():
+        if isinstance(mod, LinearProjection) and mod.to_q.bias is not None:
+            g = [mod.to_q.weight, mod.to_kv.weight, mod.to_q.bias, mod.to_kv.bias]
+            for t in g:
+                group[id(t)] = g
+    out, seen = [], set()
+    for p in root.parameters():
+        for t in group.get(id(p), [p]):
+            if id(t) not in seen:
+                seen.add(id(t))
+                out.append(t)
+    return out
 
 
 def flatten_parameters(params, device=None):
@@ -126,9 +146,10 @@ class TrainEngine:
         self.betas, self.eps = betas, eps
         self.use_graph = use_graph
         moco = net.E.E
-        enc_q = list(moco.encoder_q.parameters())
-        enc_k = list(moco.encoder_k.parameters())
-        rest = [p for p in net.parameters() if p.requires_grad and all(p is not q for q in enc_q)]
+        enc_q = ordered_parameters(moco.encoder_q)
+        enc_k = ordered_parameters(moco.encoder_k)
+        qids = {id(q) for q in enc_q}
+        rest = [p for p in ordered_parameters(net) if p.requires_grad and id(p) not in qids]
         self.trainable = enc_q + rest                      # query encoder first: its slice mirrors the key encoder
         dev = enc_q[0].device
         assert dev.type == 'cuda', 'TrainEngine needs the HIP device'
@@ -154,6 +175,7 @@ class TrainEngine:
                 for p, o in zip(plist, offs):
                     if p.dim() == 2 and (p.shape[1] * 2) % 16 == 0:
                         p._fw_shadow = sh[o:o + p.numel()].view_as(p)
+        self._fuse_projections(net)
         moco._ema_hook = self._ema
         self.allreduce = GradAllReducer(self.flat_g, wire_dtype=grad_wire_dtype)
         if dist.is_initialized() and dist.get_world_size() > 1:
@@ -164,6 +186,30 @@ class TrainEngine:
         self._graph = None
         self._static = None
         self.last = None
+
+    def _fuse_projections(self, net):
+        """to_q / to_kv of a LinearProjection lie back to back in the flat buffers (ordered_parameters): expose them as ONE
+        [3C, C] weight / [3C] bias (+ gradient and bf16 shadow views) so that QKV is one GEMM forward and two backward."""
+        from .modules import LinearProjection
+        for flat, grad, shadow in ((self.flat_p, self.flat_g, self.shadow_p), (self.flat_k, None, self.shadow_k)):
+            base = flat.data_ptr()
+            lo, hi = base, base + flat.numel() * 4
+            for mod in net.modules():
+                if not isinstance(mod, LinearProjection) or mod.to_q.bias is None:
+                    continue
+                wq, wkv, bq, bkv = mod.to_q.weight, mod.to_kv.weight, mod.to_q.bias, mod.to_kv.bias
+                C, K = wq.shape
+                if not (lo <= wq.data_ptr() < hi) or C % 8 or wkv.shape != (2 * C, K):
+                    continue
+                if wq.data_ptr() + wq.numel() * 4 != wkv.data_ptr() or bq.data_ptr() + bq.numel() * 4 != bkv.data_ptr():
+                    continue
+                ow, ob = (wq.data_ptr() - base) // 4, (bq.data_ptr() - base) // 4
+                fused = {'w': flat[ow:ow + 3 * C * K].view(3 * C, K), 'b': flat[ob:ob + 3 * C]}
+                if grad is not None:
+                    fused['gw'], fused['gb'] = grad[ow:ow + 3 * C * K].view(3 * C, K), grad[ob:ob + 3 * C]
+                if shadow is not None and (K * 2) % 16 == 0:
+                    fused['sw'] = shadow[ow:ow + 3 * C * K].view(3 * C, K)
+                mod._fw_fused = fused
 
     def set_lr(self, lr):
         self.hyper[0:1].fill_(float(lr))
@@ -203,6 +249,7 @@ class TrainEngine:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         single = self.allreduce.world == 1
+        ops.reserve_capture_tables()
         self._g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g1):
             self._out = self._fwd_bwd(*self._static)

@@ -44,7 +44,7 @@ _shadow = {}          # id(param) -> (weakref(param), {(kind, dtype): (stamp, te
 def shadow(param, kind='plain'):
     """Operand view of a parameter in the compute dtype.
     kind: 'plain' [N, K];  'conv4' [Cout, Cin, 4, 4] -> [Cout, 16*Cin] (K order ky, kx, ci);
-          'convT2' [Cin, Cout, 2, 2] -> [4*Cout, Cin] (row order i, j, co)."""
+          'convT2' [Cin, Cout, 2, 2] -> [4*Cout, Cin] (row order i, j, co);  'dw9' [C, 1, 3, 3] -> f32 [9, C]."""
     dtype = config.compute_dtype
     p = param.detach()
     fs = getattr(param, '_fw_shadow', None)
@@ -68,6 +68,10 @@ def shadow(param, kind='plain'):
         co, ci = p.shape[0], p.shape[1]
         out = torch.empty((co, 16 * ci), dtype=dtype, device=p.device)
         ops.permute3(p.contiguous(), out, (co, ci, 16), (16 * ci, 1, ci))
+    elif kind == 'dw9':
+        c = p.shape[0]
+        out = torch.empty((9, c), dtype=torch.float32, device=p.device)       # depthwise 3x3 taps, tap-major (always f32)
+        ops.permute3(p.reshape(c, 9), out, (1, c, 9), (0, 1, c))
     elif kind == 'convT2':
         ci, co = p.shape[0], p.shape[1]
         out = torch.empty((4 * co, ci), dtype=dtype, device=p.device)
@@ -101,7 +105,7 @@ def _wgrad(g, x, n, k, m, weight, bias=None):
     same pass (xsum).  Returns the autograd values (dW, db)."""
     dw, rw = _grad_target(weight, (n, k))
     db, rb = _grad_target(bias) if bias is not None else (None, None)
-    ops.wgrad(g, x, n, k, m, dw, db)
+    ops.wgrad(g, x, n, k, m, dw, db, defer=rw is None and rb is None)      # persistent .grad views only: autograd copies what it is handed
     return (rw.view_as(weight) if rw is not None else None), rb
 
 
@@ -133,7 +137,7 @@ class LayerNormFn(torch.autograd.Function):
         beta = ctx.beta
         dg, rg = _grad_target(gamma)
         db, rb = _grad_target(beta)
-        dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db)
+        dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db, defer=rg is None and rb is None)
         return dx, rg, rb
 
 
@@ -216,7 +220,7 @@ class LnResFn(torch.autograd.Function):
         db, rb = _grad_target(ctx.beta)
         if dy is None:
             return dres, None, None
-        dx = ops.layernorm_bwd(aligned(dy), x, gamma, mean, rstd, dg, db, dres=dres)
+        dx = ops.layernorm_bwd(aligned(dy), x, gamma, mean, rstd, dg, db, dres=dres, defer=rg is None and rb is None)
         return dx, rg, rb
 
 
@@ -226,18 +230,27 @@ def linear(x, weight, bias=None, residual=None, rowscale=None, rows_per_scale=1,
 
 class QKVFn(torch.autograd.Function):
     """qkv buffer [M, Cp + 2C] = [ x Wq^T + bq | pad | x Wkv^T + bkv ],  Cp = roundup(C, 8)
-    (decoder_Uformer.py:121-124: to_q and to_kv outputs, k = kv[:, :C], v = kv[:, C:])."""
+    (decoder_Uformer.py:121-124: to_q and to_kv outputs, k = kv[:, :C], v = kv[:, C:]).
+    fused: the engine's single [3C, C] view of both weights (engine.TrainEngine._fuse_projections) -> one GEMM each way."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wkv, bkv):
+    def forward(ctx, x, wq, bq, wkv, bkv, fused):
         M, K = x.shape
         C = wq.shape[0]
         Cp = (C + 7) // 8 * 8
         buf = act_empty(M, Cp + 2 * C, x.dtype, x.device)
-        ops.gemm(x, shadow(wq), M, C, K, out=buf[:, :C], bias=bq)
-        ops.gemm(x, shadow(wkv), M, 2 * C, K, out=buf[:, Cp:], bias=bkv)
+        if fused is not None and Cp == C:
+            w3 = fused['sw'] if x.dtype == torch.bfloat16 and 'sw' in fused else (fused['w'] if x.dtype == torch.float32 else None)
+        else:
+            w3 = None
+        if w3 is not None:
+            ops.gemm(x, w3, M, 3 * C, K, out=buf[:, :3 * C], bias=fused['b'])
+        else:
+            ops.gemm(x, shadow(wq), M, C, K, out=buf[:, :C], bias=bq)
+            ops.gemm(x, shadow(wkv), M, 2 * C, K, out=buf[:, Cp:], bias=bkv)
         ctx.save_for_backward(x, wq, wkv)
         ctx.bq, ctx.bkv = bq, bkv
+        ctx.fused = (fused, w3)
         return buf
 
     @staticmethod
@@ -247,14 +260,19 @@ class QKVFn(torch.autograd.Function):
         C = wq.shape[0]
         Cp = (C + 7) // 8 * 8
         dbuf = aligned(dbuf)
+        fused, w3 = ctx.fused
+        dx = act_empty(M, K, x.dtype, x.device)
+        if w3 is not None and config.direct_grads and 'gw' in fused:
+            ops.wgrad(dbuf[:, :3 * C], x, 3 * C, K, M, fused['gw'], fused['gb'], defer=True)
+            ops.gemm(dbuf[:, :3 * C], w3, M, K, 3 * C, w_trans=True, out=dx)
+            return dx, None, None, None, None, None
         dq, dkv = dbuf[:, :C], dbuf[:, Cp:]
         dwq, dbq = _wgrad(dq, x, C, K, M, wq, ctx.bq)
         dwkv, dbkv = _wgrad(dkv, x, 2 * C, K, M, wkv, ctx.bkv)
         tmp = torch.empty((M, K), dtype=torch.float32, device=x.device)
         ops.gemm(dq, shadow(wq), M, K, C, w_trans=True, out=tmp)
-        dx = act_empty(M, K, x.dtype, x.device)
         ops.gemm(dkv, shadow(wkv), M, K, 2 * C, w_trans=True, out=dx, residual=tmp)
-        return dx, dwq, dbq, dwkv, dbkv
+        return dx, dwq, dbq, dwkv, dbkv, None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -328,8 +346,7 @@ class DwConvFn(torch.autograd.Function):
         C = h1.shape[1]
         h2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
         g2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
-        wt = torch.empty((9, C), dtype=torch.float32, device=h1.device)          # tap-major copy of the [C,1,3,3] weight
-        ops.permute3(weight.detach().reshape(C, 9), wt, (1, C, 9), (0, 1, C))
+        wt = shadow(weight, 'dw9')                                               # tap-major copy of the [C,1,3,3] weight, cached per step
         call('fw_dwconv_fwd', dt(h1.dtype), g1, g1.stride(0), wt, bias, h2, g2, h2.stride(0), B, H, W, C)
         ctx.save_for_backward(h1, g1, weight, wt)
         ctx.bias = bias
@@ -345,12 +362,10 @@ class DwConvFn(torch.autograd.Function):
         B, H, W = ctx.geo
         C = h1.shape[1]
         dh2 = aligned(dh2)
-        dwt = _zeros((9, C), h1.device)
         db, rb = _grad_target(ctx.bias)
+        dw, rw = _grad_target(weight, (C, 9))                                    # the kernel adds in the parameter's layout
         dh1 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
-        call('fw_dwconv_bwd', dt(h1.dtype), dh2, dh2.stride(0), g1, h1, h1.stride(0), wt, dh1, dh1.stride(0), dwt, db, B, H, W, C)
-        dw, rw = _grad_target(weight, (C, 9))
-        ops.permute3(dwt, dw, (1, 9, C), (0, 1, 9), accumulate=True)
+        call('fw_dwconv_bwd', dt(h1.dtype), dh2, dh2.stride(0), g1, h1, h1.stride(0), wt, dh1, dh1.stride(0), dw, db, B, H, W, C)
         return dh1, None, (rw.view_as(weight) if rw is not None else None), rb, None, None, None
 
 

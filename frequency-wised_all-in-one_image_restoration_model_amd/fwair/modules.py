@@ -45,7 +45,7 @@ class LinearProjection(nn.Module):
         self.to_kv = nn.Linear(dim, inner * 2, bias=bias)
 
     def forward(self, xn):
-        return Fn.QKVFn.apply(xn, self.to_q.weight, self.to_q.bias, self.to_kv.weight, self.to_kv.bias)
+        return Fn.QKVFn.apply(xn, self.to_q.weight, self.to_q.bias, self.to_kv.weight, self.to_kv.bias, getattr(self, '_fw_fused', None))
 
 
 class LeFF(nn.Module):

@@ -42,9 +42,95 @@ def pick_splitk(M, N, K, dtype):
     return int(sk)
 
 
-def wgrad(g, x, n, k, m, dw, db=None):
+# ---- deferred reduction of split partials -------------------------------------------------------------------
+# A backward pass produces several hundred small slabs of partial sums (split weight-gradient GEMMs, LayerNorm column sums)
+# whose results nobody reads before the optimizer step.  Inside a backward pass they are queued and folded by ONE
+# fw_slab_reduce_multi launch when the pass ends (autograd engine callback) instead of one tiny launch each.
+_pending = []            # (slab, nz, n, zstride, dst, dst2, off2, n2)
+_flush_registered = [False]
+_keepalive = []          # pinned host tables referenced by captured HIP graphs (their memcpy nodes re-read them on replay)
+
+
+_HOST_WORDS = 16384      # int64 words per pinned table: room for ~1400 slabs
+_host_ring, _host_next, _host_reserved = [], [0], []
+
+
+def reserve_capture_tables(count=4):
+    """Pinned host memory cannot be allocated while a stream is being captured: the engine reserves the tables a capture
+    will consume beforehand.  A captured table is never reused (the graph's memcpy node re-reads it at every replay)."""
+    while len(_host_reserved) < count:
+        _host_reserved.append(torch.empty((_HOST_WORDS,), dtype=torch.int64, pin_memory=True))
+
+
+def _host_table(words):
+    assert words <= _HOST_WORDS, 'too many pending slabs for one table'
+    if torch.cuda.is_current_stream_capturing():
+        if not _host_reserved:
+            raise RuntimeError('fwair.ops: call reserve_capture_tables() before capturing a backward pass')
+        buf = _host_reserved.pop()
+        _keepalive.append(buf)
+        return buf[:words]
+    if len(_host_ring) < 4:
+        _host_ring.append([torch.empty((_HOST_WORDS,), dtype=torch.int64, pin_memory=True), None])
+    slot = _host_ring[_host_next[0] % len(_host_ring)]
+    _host_next[0] += 1
+    if slot[1] is not None:
+        slot[1].synchronize()                          # the async copy that last read this buffer has finished
+    slot[1] = torch.cuda.Event()
+    return slot[0][:words]
+
+
+def _in_backward():
+    return torch._C._current_graph_task_id() != -1
+
+
+def slab_reduce(slab, nz, n, zstride, dst, dst2=None, off2=0, n2=0, defer=False):
+    """dst[0:n] += sum_z slab[z][0:n];  dst2[0:n2] += sum_z slab[z][off2:off2+n2].  With defer (the destinations are persistent
+    gradient buffers, not tensors handed back to autograd) the fold waits for the end of the running backward pass."""
+    if not defer or not _in_backward():
+        call('fw_slab_reduce', slab, nz, n, zstride, dst, 1, dst2, off2, n2 if dst2 is not None else 0)
+        return
+    _pending.append((slab, nz, n, zstride, dst, dst2, off2, n2 if dst2 is not None else 0))
+    if not _flush_registered[0]:
+        _flush_registered[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_slabs)
+
+
+def flush_slabs():
+    _flush_registered[0] = False
+    if not _pending:
+        return
+    items = list(_pending)
+    _pending.clear()
+    num = len(items)
+    dev = items[0][0].device
+    host = _host_table(num * 10 + num + 1)
+    tab, prefix = host[:num * 10].view(num, 10), host[num * 10:]
+    rows, offs, total = [], [0], 0
+    for slab, nz, n, zstride, dst, dst2, off2, n2 in items:
+        end = off2 + n2 if dst2 is not None else n
+        gx = ((end + 3) // 4 + 63) // 64
+        splits = max(1, min(nz // 8, 1024 // gx))              # aim at ~1024 blocks per entry, >= 8 slab rows per block
+        zper = (nz + splits - 1) // splits
+        gy = (nz + zper - 1) // zper
+        rows.append((slab.data_ptr(), dst.data_ptr(), dst2.data_ptr() if dst2 is not None else 0, n, zstride, off2, n2, nz, zper, gx))
+        total += gx * gy
+        offs.append(total)
+    tab.copy_(torch.tensor(rows, dtype=torch.int64))
+    prefix.copy_(torch.tensor(offs, dtype=torch.int64))
+    table = torch.empty(host.shape, dtype=torch.int64, device=dev)
+    table.copy_(host, non_blocking=True)
+    call('fw_slab_reduce_multi', table, table[num * 10:], num, total)
+    if not torch.cuda.is_current_stream_capturing():
+        for slot in _host_ring:
+            if slot[0].data_ptr() == host.data_ptr():
+                slot[1].record()
+    # `items` (the slabs) die here: the allocator reuses them stream-ordered, i.e. after the kernel above
+
+
+def wgrad(g, x, n, k, m, dw, db=None, defer=False):
     """dw[n][k] += sum_m g[m][n] x[m][k];  db[n] += sum_m g[m][n].  Large reductions are split over K into a slab of
-    partial tiles (plain stores) that fw_slab_reduce folds -- no same-address atomics."""
+    partial tiles (plain stores) that a slab reduce folds -- no same-address atomics."""
     sk = pick_splitk(n, k, m, g.dtype)
     if sk == 1:
         gemm(g, x, n, k, m, x_trans=True, w_trans=True, out=dw, accumulate=True, xsum=db)
@@ -55,7 +141,7 @@ def wgrad(g, x, n, k, m, dw, db=None):
     cview = slab[0, :n * k].view(n, k)
     xs = slab[0, nk:] if db is not None else None
     gemm(g, x, n, k, m, x_trans=True, w_trans=True, out=cview, splitk=sk, xsum=xs, c_zstride=S, xsum_zstride=S if db is not None else 0)
-    call('fw_slab_reduce', slab, sk, n * k, S, dw, 1, db, nk, n if db is not None else 0)
+    slab_reduce(slab, sk, n * k, S, dw, db, nk, n, defer=defer)
 
 
 def dgrad(g, w, M, K, N, out, act=0, aux=None):
@@ -86,13 +172,14 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, defer=False):
     rows, C = x.shape
     dx = torch.empty((rows, C), dtype=torch.float32, device=x.device)
     nblk = lib().fw_layernorm_bwd_blocks(rows, C)
     partial = torch.empty((nblk, 2 * C), dtype=torch.float32, device=x.device)
     call('fw_layernorm_bwd', dt(dy.dtype), dy, _ld(dy), x, _ld(x), gamma, mean, rstd, dres,
-         _ld(dres) if dres is not None else 0, dx, _ld(dx), dgamma, dbeta, partial, rows, C)
+         _ld(dres) if dres is not None else 0, dx, _ld(dx), None, None, partial, rows, C)
+    slab_reduce(partial, nblk, C, 2 * C, dgamma, dbeta, C, C, defer=defer)
     return dx
 
 

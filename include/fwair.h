@@ -38,6 +38,10 @@ int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op, const voi
 /* split-K without atomics: slice z stores its partial tile at C + z*c_zstride (and xsum + z*xsum_zstride); this sums the slices */
 int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, float* dst2, long off2, long n2,
                    void* stream);
+/* Many slabs in one launch (ops.flush_slabs: every weight-gradient / LayerNorm partial of a backward pass is folded once,
+ * at its end).  tab: device int64 [num][10] = slab, dst, dst2, n, zstride, off2, n2, nz, zper, gx; prefix: device int64
+ * [num + 1] block offsets (entry e owns gx * ceil(nz / zper) blocks).  Every entry ACCUMULATES into dst / dst2. */
+int fw_slab_reduce_multi(const void* tab, const void* prefix, int num, long total_blocks, void* stream);
 
 /* ---- LayerNorm over the f32 stream -> T (decoder_Uformer.py:567,594,666,744; encoder_Uformer.py:941) -- */
 int fw_layernorm_fwd(int dtype, const float* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
@@ -70,7 +74,8 @@ int fw_attn_bwd(int dtype, int D, int nkt, int lfs, const void* q, const void* k
 
 /* ---- LeFF depthwise 3x3 (net/utils/leff.py:104-111).  Both pre-activations (h) and GELU outputs (g) are kept:
  * fwd: h2 = dwconv(g1) + bias, g2 = GELU(h2);  bwd: dh1 = GELU'(h1) * convT(dh2), dw/dbias accumulated.
- * w and dw are TAP-MAJOR f32 [9][C] (the host permutes the [C,1,3,3] parameter / gradient). */
+ * w is TAP-MAJOR f32 [9][C] (a per-step permuted copy of the [C,1,3,3] parameter); dw is ACCUMULATED into in the
+ * parameter's own [C][9] layout, dbias likewise ([C]). */
 int fw_dwconv_fwd(int dtype, const void* g1, long ld1, const float* w, const float* bias, void* h2, void* g2, long ld2, int B,
                   int H, int W, int C, void* stream);
 int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g1, const void* h1, long ld1, const float* w, void* dh1,

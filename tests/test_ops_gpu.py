@@ -306,10 +306,10 @@ def test_dwconv(dtype):
     close(g2, F.gelu(ref), TOL[dtype], 'g2')
     dh2 = q(rnd(B * H * W, C, seed=3), dtype)
     ref.backward(dh2)
-    dw, db = torch.zeros(9, C, device=DEV), torch.zeros(C, device=DEV)
+    dw, db = torch.zeros(C, 9, device=DEV), torch.zeros(C, device=DEV)
     dh1 = ops().dwconv_bwd(dh2.to(DEV, dtype), g1.to(DEV, dtype), h1.detach().to(DEV, dtype), wt, dw, db, B, H, W)
     close(dh1, h1.grad, TOL[dtype] * 2, 'dh1')
-    close(dw.t(), w.grad.view(C, 9), TOL[dtype] * 2, 'dw')
+    close(dw, w.grad.view(C, 9), TOL[dtype] * 2, 'dw')
     close(db, b.grad, TOL[dtype] * 2, 'db')
 
 

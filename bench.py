@@ -61,60 +61,106 @@ def make_opt(batch, dtype):
                                  learnable_modulator=False, compute_dtype=dtype, de_type=['denoising_25'] * batch)
 
 
-def gemm_profile(engine, batch, steps=2):
-    """HIP-event timing of every fw_gemm launch of `steps` eager training steps, on the stream the kernels run on.
-    Per launch: algorithmic FLOPs 2*M*N*K and algorithmic bytes = every operand / result element touched once
-    (X, W, C, plus the optional f32 residual, aux, second output)."""
+def gemm_profile(engine, batch, reps=8):
+    """Per-launch GPU time of every distinct fw_gemm call of one training step.
+
+    Pass 1 runs one eager step with a hook that records the signature of each launch (shapes, strides, dtypes, epilogue
+    flags).  Pass 2 re-creates operands of each DISTINCT signature and times `reps` back-to-back launches inside a captured
+    HIP graph with HIP events on the capture stream -- the same launch path the timed region uses, so the numbers are
+    kernel durations (they agree with rocprofv3's per-kernel averages), free of host launch gaps.
+    Per launch: algorithmic FLOPs 2*M*N*K and algorithmic bytes = every operand / result element touched once."""
     from fwair import ops
     rec = []
     orig = ops.gemm
 
-    def timed(x, w, M, N, K, **kw):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
+    def spec(t):
+        return None if t is None else (tuple(t.shape), tuple(t.stride()), t.dtype)
+
+    def hook(x, w, M, N, K, **kw):
         r = orig(x, w, M, N, K, **kw)
-        b.record()
+        tens = {k: spec(v) for k, v in kw.items() if isinstance(v, torch.Tensor)}
+        tens['x'], tens['w'] = spec(x), spec(w)
+        if 'out' not in tens:
+            tens['out'] = spec(r)
+        scal = tuple(sorted((k, v) for k, v in kw.items() if not isinstance(v, torch.Tensor) and v is not None and k != 'out_dtype'))
+        rec.append(((M, N, K), tuple(sorted(tens.items())), scal))
+        return r
+
+    ops.gemm = hook
+    try:
+        engine.step_eager(*batch)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm = orig
+    counts = {}
+    for sig in rec:
+        counts[sig] = counts.get(sig, 0) + 1
+
+    def make(sp):
+        shape, stride, dtype = sp
+        n = 1 + sum((d - 1) * st for d, st in zip(shape, stride))
+        base = (torch.randn(n, device='cuda') * 0.5).to(dtype)
+        return torch.as_strided(base, shape, stride)
+
+    side = torch.cuda.Stream()
+    out = []
+    for (M, N, K), tens, scal in counts:
+        cnt = counts[((M, N, K), tens, scal)]
+        t = {k: make(v) for k, v in tens}
+        kw = dict(scal)
+        x, w = t.pop('x'), t.pop('w')
+        kw.update(t)
+        zs = int(kw.get('c_zstride', 0) or 0)
+        if zs > 0:                                   # split-K slab (ops.wgrad / ops.dgrad): every z slice must exist
+            sk_ = int(kw['splitk'])
+            slab = torch.zeros((sk_ + 1) * zs, dtype=torch.float32, device='cuda')
+            kw['out'] = slab[:M * N].view(M, N)
+            if kw.get('xsum') is not None:
+                nk = (M * N + 3) // 4 * 4
+                assert int(kw.get('xsum_zstride', 0)) == zs and nk + M <= zs
+                kw['xsum'] = slab[nk:zs]
+        with torch.cuda.stream(side):
+            orig(x, w, M, N, K, **kw)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(reps):
+                    orig(x, w, M, N, K, **kw)
+            g.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            g.replay()
+            e1.record(side)
+            torch.cuda.synchronize()
+        dt = e0.elapsed_time(e1) * 1e-3 / reps
         sz = x.element_size()
         sk = max(1, int(kw.get('splitk', 1) or 1))
-        by = (M * K + N * K) * sz + M * N * r.element_size() * sk
+        by = (M * K + N * K) * sz + M * N * kw['out'].element_size() * sk
         if kw.get('accumulate'):
-            by += M * N * r.element_size()
+            by += M * N * kw['out'].element_size()
         for key in ('residual', 'aux', 'out_gelu'):
-            t = kw.get(key)
-            if t is not None:
-                by += M * N * t.element_size()
+            if kw.get(key) is not None:
+                by += M * N * kw[key].element_size()
         stream = (not kw.get('x_trans') and sk == 1 and not kw.get('accumulate') and not kw.get('x_op') and not kw.get('w_op')
                   and kw.get('xsum') is None and K * sz <= 512 and M >= 32768)          # fw_gemm's dispatch rule
         variant = ('bf16' if x.dtype == torch.bfloat16 else 'f32', 'stream' if stream else (64 if N <= 64 else 128),
                    bool(kw.get('x_trans')), bool(kw.get('w_trans')))
-        rec.append((variant, (M, N, K, sk), 2.0 * M * N * K, float(by), a, b))
-        return r
-
-    ops.gemm = timed
-    try:
-        for _ in range(steps):
-            engine.step_eager(*batch)
-        torch.cuda.synchronize()
-    finally:
-        ops.gemm = orig
-    agg, shapes = {}, {}
-    for variant, shape, fl, by, a, b in rec:
-        t = a.elapsed_time(b) * 1e-3
+        out.append((variant, (M, N, K, sk), cnt, 2.0 * M * N * K, float(by), dt))
+        del g, t, kw, x, w
+    agg = {}
+    for variant, shape, cnt, fl, by, dt in out:
         d = agg.setdefault(variant, [0.0, 0.0, 0, 0.0, 0.0])
-        d[0] += fl; d[1] += t; d[2] += 1; d[3] += by
-        d[4] += max(fl / PEAK_FOR[variant[0]], by / PEAK_HBM)          # time the launch would take at its roofline
-        e = shapes.setdefault((variant, shape), [0.0, 0.0, 0, 0.0])
-        e[0] += fl; e[1] += t; e[2] += 1; e[3] += by
+        d[0] += fl * cnt; d[1] += dt * cnt; d[2] += cnt; d[3] += by * cnt
+        d[4] += cnt * max(fl / PEAK_FOR[variant[0]], by / PEAK_HBM)          # time the launches would take at their roofline
     dump = os.environ.get('FW_GEMM_DUMP')
     if dump:
         with open(dump, 'w') as f:
-            f.write('dtype,BN,xT,wT,M,N,K,splitk,launches_per_step,us_per_launch,ms_per_step,TFLOPs,GBs,roofline_us\n')
-            for (v, sh), e in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
-                n = e[2]
-                roof = max(e[0] / n / PEAK_FOR[v[0]], e[3] / n / PEAK_HBM) * 1e6
-                f.write(f'{v[0]},{v[1]},{int(v[2])},{int(v[3])},{sh[0]},{sh[1]},{sh[2]},{sh[3]},{n / steps:g},{e[1] / n * 1e6:.1f},'
-                        f'{e[1] / steps * 1e3:.3f},{e[0] / e[1] / 1e12:.1f},{e[3] / e[1] / 1e9:.0f},{roof:.1f}\n')
-    return agg, len(rec) // steps
+            f.write('dtype,kernel,xT,wT,M,N,K,splitk,launches_per_step,us_per_launch,ms_per_step,TFLOPs,GBs,roofline_us\n')
+            for v, sh, cnt, fl, by, dt in sorted(out, key=lambda r: -r[2] * r[5]):
+                roof = max(fl / PEAK_FOR[v[0]], by / PEAK_HBM) * 1e6
+                f.write(f'{v[0]},{v[1]},{int(v[2])},{int(v[3])},{sh[0]},{sh[1]},{sh[2]},{sh[3]},{cnt},{dt * 1e6:.1f},'
+                        f'{dt * cnt * 1e3:.3f},{fl / dt / 1e12:.1f},{by / dt / 1e9:.0f},{roof:.1f}\n')
+    return agg, len(rec)
 
 
 def cpu_baseline(threads):
@@ -234,7 +280,7 @@ def main():
     peak = PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32_MFMA
     res['step_mfma_fraction'] = round(ips / world * FLOP_PER_IMAGE_STEP / peak, 5)
     if rank == 0 and world == 1 and not args.no_profile:
-        log('timing every GEMM launch of two eager steps with HIP events ...')
+        log('timing every distinct GEMM launch of the step (HIP events around captured replays) ...')
         agg, launches = gemm_profile(eng, data)
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         tot_t = sum(v[1] for v in agg.values())
@@ -242,13 +288,14 @@ def main():
         # the variant's launches are priced one by one against max(FLOPs / MFMA peak, bytes / HBM peak); `bound` is the
         # side that sets most of that time, `achieved` / `peak` are quoted in its unit, `frac` = roofline time / measured
         hbm = by / PEAK_HBM > fl / peak
-        res['roofline'] = {'bound': 'hbm' if hbm else 'mfma', 'kernel': (f'gemm_stream_kernel<{v[0]},wT={int(v[3])}>' if v[1] == 'stream' else f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>'),
+        res['roofline'] = {'bound': 'hbm' if hbm else 'mfma',
+                           'kernel': (f'gemm_stream_kernel<{v[0]},wT={int(v[3])}>' if v[1] == 'stream' else f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>'),
                            'achieved': round((by / tt / 1e9) if hbm else (fl / tt / 1e12), 2),
                            'peak': (PEAK_HBM / 1e9) if hbm else (peak / 1e12), 'unit': 'GB/s' if hbm else 'TFLOP/s',
                            'frac': round(troof / tt, 5), 'traffic': None, 'avg_launch_us': round(tt / cnt * 1e6, 2),
                            'tflops': round(fl / tt / 1e12, 2), 'algorithmic_gbs': round(by / tt / 1e9, 1),
-                           'launches_per_step': cnt // 2, 'gemm_launches_per_step': launches,
-                           'gemm_time_ms_per_step': round(tot_t / 2 * 1e3, 3),
+                           'launches_per_step': cnt, 'gemm_launches_per_step': launches,
+                           'gemm_time_ms_per_step': round(tot_t * 1e3, 3),
                            'all_gemm_tflops': round(sum(x[0] for x in agg.values()) / tot_t / 1e12, 2),
                            'all_gemm_roofline_frac': round(sum(x[4] for x in agg.values()) / tot_t, 5)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

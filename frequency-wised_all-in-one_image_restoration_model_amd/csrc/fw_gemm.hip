@@ -255,11 +255,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     auto ws = [&](int i) -> char* { return smem + i * (XBYTES + WBYTES) + XBYTES; };
 
     const int wave = threadIdx.x >> 6;
-    const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+    // Workgroups are dealt round-robin to the 8 XCDs (8 private L2s).  With split-K every output tile of one K slice reads the
+    // same token rows: keep a slice's tiles on ONE XCD (slices z = xcd, xcd + 8, ...) so its operands are fetched into one L2
+    // instead of eight.  (Without split-K, tiles sharing X rows are gridDim.x apart and already meet when gridDim.x % 8 == 0.)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (gridDim.z >= 8 && (gridDim.z & 7) == 0) {
+        const unsigned nt = gridDim.x * gridDim.y;
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned r = lin >> 3, t = r % nt;
+        bz = (int)((r / nt) * 8 + (lin & 7));
+        bx = (int)(t % gridDim.x); by = (int)(t / gridDim.x);
+    }
+    const int m_blk = bx * BM, n_blk = by * BN;
     const int wm0 = (BN == 128) ? (wave & 1) * 64 : wave * 32;
     const int wn0 = (BN == 128) ? (wave >> 1) * 64 : 0;
 
-    const int k_begin = blockIdx.z * a.kper;
+    const int k_begin = bz * a.kper;
     const int k_end = min(a.K, k_begin + a.kper);
     const int nsteps = (k_end - k_begin + KT - 1) / KT;
 
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     float xsum[TT<T>::E16];
 #pragma unroll
     for (int e = 0; e < TT<T>::E16; ++e) xsum[e] = 0.f;
-    const bool do_xsum = XT && a.xsum != nullptr && blockIdx.y == 0;
+    const bool do_xsum = XT && a.xsum != nullptr && by == 0;
     if (nsteps > 0) {
         if constexpr (GX) glds_issue<T, BM>(a.X, a.ldx, m_blk, a.M, k_begin * TT<T>::SZ, xs(0));
         else { sx.fetch(a.X, a.ldx, m_blk, a.M, k_begin, k_end, a.x_op); if (do_xsum) sx.accum(xsum); }
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     }
 
     if constexpr (XT) {
-        if (a.xsum != nullptr && blockIdx.y == 0) {          // block-uniform: reduce the 16 k-slices on chip, one atomic per row
+        if (a.xsum != nullptr && by == 0) {          // block-uniform: reduce the 16 k-slices on chip, one atomic per row
             constexpr int E = TT<T>::E16, IB = BM / E;
             float* red = reinterpret_cast<float*>(smem);       // the staging tiles are dead after the last barrier
             if (threadIdx.x < BM) red[threadIdx.x] = 0.f;
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
             }
             __syncthreads();
             if (threadIdx.x < BM && m_blk + (int)threadIdx.x < a.M) {
-                if (a.xsum_zstride > 0) a.xsum[(long)blockIdx.z * a.xsum_zstride + m_blk + threadIdx.x] = red[threadIdx.x];
+                if (a.xsum_zstride > 0) a.xsum[(long)bz * a.xsum_zstride + m_blk + threadIdx.x] = red[threadIdx.x];
                 else atomicAdd(a.xsum + m_blk + threadIdx.x, red[threadIdx.x]);
             }
         }
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         for (int nt = 0; nt < 4; ++nt) {
             const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
             if (n0 >= a.N) continue;
-            epi_quad<T>(a, acc[nt][mt], m, n0, rs, blockIdx.z);
+            epi_quad<T>(a, acc[nt][mt], m, n0, rs, bz);
         }
     }
 }

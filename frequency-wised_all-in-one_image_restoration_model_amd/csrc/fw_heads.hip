@@ -25,70 +25,72 @@ template <int N> FW_DEV float block_sum(float v, float* red) {      // N threads
 // 2-D DFT band decomposition, one image per workgroup, N <= 128
 // =====================================================================================================
 // spectrum (unshifted) F[u][v] = sum_{y,x} img[y][x] exp(-2 pi i (u y + v x) / N)  ->  fr, fi [n][N][N]
+// One workgroup = 16 output rows of one image (grid: image x row slice): 8x the parallelism of one image per workgroup, and
+// no redundant work because each slice contracts over y FIRST:  F[u][v] = sum_x ( sum_y img[y][x] w^{uy} ) w^{xv},  w = e^{-2 pi i/N}.
+constexpr int DFT_SL = 16;
 __global__ __launch_bounds__(256) void dft2_fwd_kernel(const float* __restrict__ img, float* __restrict__ fr, float* __restrict__ fi, int N) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* gr = sm;                 // [N][N]  G[y][v] real
-    float* gi = sm + N * N;         // imag
-    float* tc = sm + 2 * N * N;     // cos(2 pi k / N)
-    float* ts = tc + N;             // sin
+    __shared__ float hr[DFT_SL * 128], hi[DFT_SL * 128], tc[128], ts[128];
+    const int rows = N < DFT_SL ? N : DFT_SL;
+    const int u0 = blockIdx.y * rows;
     const float* x = img + (size_t)blockIdx.x * N * N;
-    for (int k = threadIdx.x; k < N; k += 256) { float s, c; sincospif(2.0f * k / N, &s, &c); tc[k] = c; ts[k] = s; }
+    for (int k = threadIdx.x; k < N; k += 256) { float sn, cs; sincospif(2.0f * k / N, &sn, &cs); tc[k] = cs; ts[k] = sn; }
     __syncthreads();
-    for (int o = threadIdx.x; o < N * N; o += 256) {          // rows: G[y][v] = sum_x img[y][x] e^{-i 2pi x v/N}
-        const int y = o / N, v = o % N;
-        float ar = 0.f, ai = 0.f;
-        for (int xx = 0; xx < N; ++xx) {
-            const float p = x[y * N + xx];
-            const int k = (xx * v) & (N - 1);
-            ar += p * tc[k]; ai -= p * ts[k];
-        }
-        gr[o] = ar; gi[o] = ai;
-    }
-    __syncthreads();
-    float* outr = fr + (size_t)blockIdx.x * N * N;
-    float* outi = fi + (size_t)blockIdx.x * N * N;
-    for (int o = threadIdx.x; o < N * N; o += 256) {          // cols: F[u][v] = sum_y G[y][v] e^{-i 2pi y u/N}
-        const int u = o / N, v = o % N;
+    for (int o = threadIdx.x; o < rows * N; o += 256) {       // H[u][x] = sum_y img[y][x] e^{-i 2pi y u/N}
+        const int u = u0 + o / N, xx = o % N;
         float ar = 0.f, ai = 0.f;
         for (int y = 0; y < N; ++y) {
+            const float p = x[y * N + xx];
             const int k = (y * u) & (N - 1);
-            const float c = tc[k], s = ts[k], a = gr[y * N + v], b = gi[y * N + v];
-            ar += a * c + b * s; ai += b * c - a * s;
-        }
-        outr[o] = ar; outi[o] = ai;
-    }
-}
-// band image: out[band][n][y][x] = Re( IDFT2( mask_band * F ) ),  mask in UNSHIFTED coordinates [nb][N][N]
-__global__ __launch_bounds__(256) void dft2_band_inv_kernel(const float* __restrict__ fr, const float* __restrict__ fi, const float* __restrict__ mask,
-                                                            float* __restrict__ out, int N, int nimg) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* hr = sm; float* hi = sm + N * N; float* tc = sm + 2 * N * N; float* ts = tc + N;
-    const int n = blockIdx.x, band = blockIdx.y;
-    const float* Fr = fr + (size_t)n * N * N; const float* Fi = fi + (size_t)n * N * N;
-    const float* M = mask + (size_t)band * N * N;
-    for (int k = threadIdx.x; k < N; k += 256) { float s, c; sincospif(2.0f * k / N, &s, &c); tc[k] = c; ts[k] = s; }
-    __syncthreads();
-    for (int o = threadIdx.x; o < N * N; o += 256) {          // H[u][x] = sum_v M F[u][v] e^{+i 2pi v x/N}
-        const int u = o / N, xx = o % N;
-        float ar = 0.f, ai = 0.f;
-        for (int v = 0; v < N; ++v) {
-            const float m = M[u * N + v];
-            if (m == 0.f) continue;
-            const int k = (v * xx) & (N - 1);
-            const float c = tc[k], s = ts[k], a = Fr[u * N + v], b = Fi[u * N + v];
-            ar += a * c - b * s; ai += a * s + b * c;
+            ar += p * tc[k]; ai -= p * ts[k];
         }
         hr[o] = ar; hi[o] = ai;
     }
     __syncthreads();
-    float* o_ = out + ((size_t)band * nimg + n) * N * N;
-    const float inv = 1.0f / (N * N);
-    for (int o = threadIdx.x; o < N * N; o += 256) {          // out[y][x] = Re sum_u H[u][x] e^{+i 2pi u y/N} / N^2
-        const int y = o / N, xx = o % N;
-        float ar = 0.f;
+    float* outr = fr + (size_t)blockIdx.x * N * N + (size_t)u0 * N;
+    float* outi = fi + (size_t)blockIdx.x * N * N + (size_t)u0 * N;
+    for (int o = threadIdx.x; o < rows * N; o += 256) {       // F[u][v] = sum_x H[u][x] e^{-i 2pi x v/N}
+        const int ul = o / N, v = o % N;
+        float ar = 0.f, ai = 0.f;
+        for (int xx = 0; xx < N; ++xx) {
+            const int k = (xx * v) & (N - 1);
+            const float c = tc[k], sn = ts[k], a = hr[ul * N + xx], b = hi[ul * N + xx];
+            ar += a * c + b * sn; ai += b * c - a * sn;
+        }
+        outr[o] = ar; outi[o] = ai;
+    }
+}
+// band image: out[band][n][y][x] = Re( IDFT2( mask_band * F ) ),  mask in UNSHIFTED coordinates [nb][N][N].
+// Same slicing (grid: image x band x 16-row slice of y):  out[y][x] = Re sum_v ( sum_u M F[u][v] w^{-uy} ) w^{-vx} / N^2.
+__global__ __launch_bounds__(256) void dft2_band_inv_kernel(const float* __restrict__ fr, const float* __restrict__ fi, const float* __restrict__ mask,
+                                                            float* __restrict__ out, int N, int nimg) {
+    __shared__ float kr[DFT_SL * 128], ki[DFT_SL * 128], tc[128], ts[128];
+    const int rows = N < DFT_SL ? N : DFT_SL;
+    const int n = blockIdx.x, band = blockIdx.y, y0 = blockIdx.z * rows;
+    const float* Fr = fr + (size_t)n * N * N; const float* Fi = fi + (size_t)n * N * N;
+    const float* M = mask + (size_t)band * N * N;
+    for (int k = threadIdx.x; k < N; k += 256) { float sn, cs; sincospif(2.0f * k / N, &sn, &cs); tc[k] = cs; ts[k] = sn; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < rows * N; o += 256) {       // K[y][v] = sum_u M F[u][v] e^{+i 2pi u y/N}
+        const int y = y0 + o / N, v = o % N;
+        float ar = 0.f, ai = 0.f;
         for (int u = 0; u < N; ++u) {
+            const float m = M[u * N + v];
+            if (m == 0.f) continue;
             const int k = (u * y) & (N - 1);
-            ar += hr[u * N + xx] * tc[k] - hi[u * N + xx] * ts[k];
+            const float c = tc[k], sn = ts[k], a = Fr[u * N + v] * m, b = Fi[u * N + v] * m;
+            ar += a * c - b * sn; ai += a * sn + b * c;
+        }
+        kr[o] = ar; ki[o] = ai;
+    }
+    __syncthreads();
+    float* o_ = out + ((size_t)band * nimg + n) * N * N + (size_t)y0 * N;
+    const float inv = 1.0f / (N * N);
+    for (int o = threadIdx.x; o < rows * N; o += 256) {       // out[y][x] = Re sum_v K[y][v] e^{+i 2pi v x/N} / N^2
+        const int yl = o / N, xx = o % N;
+        float ar = 0.f;
+        for (int v = 0; v < N; ++v) {
+            const int k = (v * xx) & (N - 1);
+            ar += kr[yl * N + v] * tc[k] - ki[yl * N + v] * ts[k];
         }
         o_[o] = ar * inv;
     }
@@ -424,10 +426,7 @@ __global__ __launch_bounds__(64) void lfs_lambda_bwd_kernel(const float* __restr
 // spectrum scratch fr/fi: [nimg][N][N] f32 each.
 extern "C" int fw_dft2_fwd(const float* img, float* fr, float* fi, int nimg, int N, void* stream) {
     FW_CHECK_ARG(img && fr && fi && nimg > 0 && N >= 8 && N <= 128 && (N & (N - 1)) == 0);
-    const size_t lds = (size_t)(2 * N * N + 2 * N) * 4;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dft2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); done = true; }
-    hipLaunchKernelGGL(dft2_fwd_kernel, dim3(nimg), dim3(256), lds, ST, img, fr, fi, N);
+    hipLaunchKernelGGL(dft2_fwd_kernel, dim3(nimg, N < DFT_SL ? 1 : N / DFT_SL), dim3(256), 0, ST, img, fr, fi, N);
     FW_LAUNCH_RET();
 }
 // mode 0: real band images (inverse=True) out [nb][nimg][N][N];  1: (re,im) pairs out [nb][nimg][N][N][2];  2: |.| fftshift-ed ('visual')
@@ -435,10 +434,7 @@ extern "C" int fw_dft2_bands(const float* fr, const float* fi, const float* mask
                              int mode, void* stream) {
     FW_CHECK_ARG(fr && fi && mask_unshifted && out && nimg > 0 && N >= 8 && N <= 128 && (N & (N - 1)) == 0 && nbands > 0 && mode >= 0 && mode <= 2);
     if (mode == 0) {
-        const size_t lds = (size_t)(2 * N * N + 2 * N) * 4;
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dft2_band_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); done = true; }
-        hipLaunchKernelGGL(dft2_band_inv_kernel, dim3(nimg, nbands), dim3(256), lds, ST, fr, fi, mask_unshifted, out, N, nimg);
+        hipLaunchKernelGGL(dft2_band_inv_kernel, dim3(nimg, nbands, N < DFT_SL ? 1 : N / DFT_SL), dim3(256), 0, ST, fr, fi, mask_unshifted, out, N, nimg);
     } else {
         hipLaunchKernelGGL(dft2_band_spec_kernel, dim3(nimg, nbands), dim3(256), 0, ST, fr, fi, mask_unshifted, out, N, nimg, mode - 1);
     }

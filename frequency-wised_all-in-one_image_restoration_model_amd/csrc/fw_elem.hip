@@ -5,6 +5,7 @@
 // Everything here is bandwidth work: 16-byte accesses along channels, grid-stride loops, block-level
 // partial sums before atomics.
 #include "fw_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -17,6 +18,19 @@ template <typename T> FW_DEV void ldvec(const T* p, float* f) {       // E16 ele
     unpack16<T>(*reinterpret_cast<const uint4*>(p), f);
 }
 template <typename T> FW_DEV void stvec(T* p, const float* f) { *reinterpret_cast<uint4*>(p) = pack16<T>(f); }
+// 4-element vectors (16 B of f32 / 8 B of bf16): half the registers per thread of the 16-byte form -> twice the waves in flight
+template <typename T> FW_DEV void ldvec4(const T* p, float* f);
+template <> FW_SPEC void ldvec4<float>(const float* p, float* f) { unpack16<float>(*reinterpret_cast<const uint4*>(p), f); }
+template <> FW_SPEC void ldvec4<bf16raw>(const bf16raw* p, float* f) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <typename T> FW_DEV void stvec4(T* p, const float* f);
+template <> FW_SPEC void stvec4<float>(float* p, const float* f) { *reinterpret_cast<uint4*>(p) = pack16<float>(f); }
+template <> FW_SPEC void stvec4<bf16raw>(bf16raw* p, const float* f) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]));
+}
 
 // ------------------------------------------------------------------------------------------------
 // cast / copy / axpy
@@ -87,11 +101,32 @@ __global__ void permute3_kernel(const TI* __restrict__ in, TO* __restrict__ out,
 // ------------------------------------------------------------------------------------------------
 constexpr int SX = 8;     // strip length (W is a multiple of 8 everywhere in the model)
 
-// MODE 0: forward (writes out = conv + bias and out2 = GELU(out));  MODE 1: data gradient (flipped taps, times GELU'(pre))
+// Raw 4-element vectors (16 B of f32 / 8 B of bf16) kept packed in registers until they are consumed.
+template <typename T> struct Raw4;
+template <> struct Raw4<float> {
+    uint4 v;
+    FW_MEM void load(const float* p) { v = *reinterpret_cast<const uint4*>(p); }
+    FW_MEM void zero_unless(bool ok) { if (!ok) v = make_uint4(0, 0, 0, 0); }
+    FW_MEM void unpack(float* f) const { unpack16<float>(v, f); }
+};
+template <> struct Raw4<bf16raw> {
+    uint2 v;
+    FW_MEM void load(const bf16raw* p) { v = *reinterpret_cast<const uint2*>(p); }
+    FW_MEM void zero_unless(bool ok) { if (!ok) v = make_uint2(0, 0); }
+    FW_MEM void unpack(float* f) const {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+};
+
+// MODE 0: forward (writes out = conv + bias and out2 = GELU(out));  MODE 1: data gradient (flipped taps, times GELU'(pre)).
+// Branch-free: out-of-image taps are read from CLAMPED coordinates and zeroed by a select, so the 30 (+8) loads of a thread are
+// independent instructions the compiler issues back to back -- with a branch around every edge load each load waited for the
+// previous one (a chain of 30 memory latencies per thread: 2 TB/s instead of the ~5 TB/s this access pattern streams at).
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__ in, long ldi, const float* __restrict__ w, const float* __restrict__ bias,
                                     const T* __restrict__ pre, T* __restrict__ out, T* __restrict__ out2, long ldo, int B, int H, int W, int C) {
-    constexpr int E = TT<T>::E16;
+    constexpr int E = 4;                                   // channels per thread
     const int nv = C / E, ns = W / SX;
     const long total = (long)B * H * ns * nv;
     // workgroups are dealt round-robin to the 8 XCDs (8 private L2s): give every XCD one CONTIGUOUS eighth of the rows, so
@@ -102,6 +137,26 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
         const int sx = (int)(t % ns); t /= ns;
         const int y = (int)(t % H); const long b = t / H;
         const int c0 = v * E, x0 = sx * SX;
+        // ---- all loads first ----
+        Raw4<T> raw[3][SX + 2];
+        const bool left_ok = x0 > 0, right_ok = x0 + SX < W;
+        const int xl = left_ok ? x0 - 1 : 0, xr = right_ok ? x0 + SX : W - 1;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            int yy = y + ky - 1;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            const T* row = in + ((b * H + yy) * W) * ldi + c0;
+            raw[ky][0].load(row + (long)xl * ldi);
+#pragma unroll
+            for (int cx = 0; cx < SX; ++cx) raw[ky][cx + 1].load(row + (long)(x0 + cx) * ldi);
+            raw[ky][SX + 1].load(row + (long)xr * ldi);
+        }
+        const long tok0 = (b * H + y) * W + x0;
+        Raw4<T> rpre[MODE == 1 ? SX : 1];
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int o = 0; o < SX; ++o) rpre[o].load(pre + (tok0 + o) * ldi + c0);
+        }
         float wr[E][9], acc[SX][E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -111,17 +166,16 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
 #pragma unroll
             for (int o = 0; o < SX; ++o) acc[o][e] = b0;
         }
+        // ---- then the arithmetic ----
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int yy = y + ky - 1;
-            if (yy < 0 || yy >= H) continue;
-            const T* row = in + ((b * H + yy) * W) * ldi + c0;
+            const bool row_ok = (y + ky - 1 >= 0) && (y + ky - 1 < H);
 #pragma unroll
             for (int cx = -1; cx <= SX; ++cx) {
-                const int xx = x0 + cx;
-                if (xx < 0 || xx >= W) continue;
+                Raw4<T> r = raw[ky][cx + 1];
+                r.zero_unless(row_ok && (cx >= 0 || left_ok) && (cx < SX || right_ok));
                 float f[E];
-                ldvec<T>(row + (long)xx * ldi, f);
+                r.unpack(f);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int o = cx - kx + 1;
@@ -132,20 +186,19 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
                 }
             }
         }
-        const long tok0 = (b * H + y) * W + x0;
 #pragma unroll
         for (int o = 0; o < SX; ++o) {
             if (MODE == 0) {
-                stvec<T>(out + (tok0 + o) * ldo + c0, acc[o]);
+                stvec4<T>(out + (tok0 + o) * ldo + c0, acc[o]);
 #pragma unroll
                 for (int e = 0; e < E; ++e) acc[o][e] = gelu_f(acc[o][e]);
-                stvec<T>(out2 + (tok0 + o) * ldo + c0, acc[o]);
+                stvec4<T>(out2 + (tok0 + o) * ldo + c0, acc[o]);
             } else {
                 float hc[E];
-                ldvec<T>(pre + (tok0 + o) * ldi + c0, hc);
+                rpre[o].unpack(hc);
 #pragma unroll
                 for (int e = 0; e < E; ++e) acc[o][e] *= gelu_grad_f(hc[e]);
-                stvec<T>(out + (tok0 + o) * ldo + c0, acc[o]);
+                stvec4<T>(out + (tok0 + o) * ldo + c0, acc[o]);
             }
         }
     }
@@ -156,7 +209,7 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dh2, long ldg, const T* __restrict__ g1, long ld1,
                                                            float* __restrict__ dw, float* __restrict__ dbias, int B, int H, int W, int C, int NSTRIP) {
-    constexpr int E = TT<T>::E16;
+    constexpr int E = 4;                                   // channels per thread
     __shared__ float red[8 * E * 10];
     const int nv = C / E, ns = W / SX;
     const int nvg = (nv + 7) / 8;
@@ -174,13 +227,13 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
         for (int e = 0; e < E; ++e) gw[k][e] = 0.f;
     if (live)
         for (long s = s0; s < nstrips && s < s0 + NSTRIP; ++s) {
-            const int sx = (int)(s % ns); const int y = (int)((s / ns) % H); const long b = s / ((long)ns * H);
+            const int y = (int)(s % H); const int sx = (int)((s / H) % ns); const long b = s / ((long)ns * H);      // walk down a column
             const int x0 = sx * SX;
             float d[SX][E];
             const T* drow = dh2 + ((b * H + y) * W + x0) * ldg + c0;
 #pragma unroll
             for (int o = 0; o < SX; ++o) {
-                ldvec<T>(drow + (long)o * ldg, d[o]);
+                ldvec4<T>(drow + (long)o * ldg, d[o]);
 #pragma unroll
                 for (int e = 0; e < E; ++e) gw[9][e] += d[o][e];
             }
@@ -194,7 +247,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
                     const int xx = x0 + cx;
                     if (xx < 0 || xx >= W) continue;
                     float f[E];
-                    ldvec<T>(row + (long)xx * ld1, f);
+                    ldvec4<T>(row + (long)xx * ld1, f);
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int o = cx - kx + 1;
@@ -701,7 +754,7 @@ extern "C" int fw_dwconv_fwd(int dtype, const void* g1, long ld1, const float* w
                              int B, int H, int W, int C, void* stream) {
     const int e = dtype == FW_DT_BF16 ? 8 : 4;
     FW_CHECK_ARG(g1 && w && bias && h2 && g2 && C % e == 0 && ld1 % e == 0 && ld2 % e == 0 && W % SX == 0);
-    const long n = (long)B * H * (W / SX) * (C / e);
+    const long n = (long)B * H * (W / SX) * (C / 4);
     const dim3 grid((unsigned)((grid_for(n) + 7) / 8 * 8));            // multiple of 8: XCD-contiguous block mapping
     if (dtype == FW_DT_BF16)
         hipLaunchKernelGGL((dwconv_strip_kernel<bf16raw, 0>), grid, dim3(TPB), 0, ST, (const bf16raw*)g1, ld1, w, bias, (const bf16raw*)nullptr,
@@ -716,8 +769,8 @@ extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g
     const int e = dtype == FW_DT_BF16 ? 8 : 4;
     FW_CHECK_ARG(dh2 && g1 && h1 && w && dh1 && dw && dbias && C % e == 0 && ld1 % e == 0 && ldg % e == 0 && ldo % e == 0 && W % SX == 0);
     FW_CHECK_ARG(ldg == ld1);                      // the data-gradient strip kernel walks dh2 and h1 with one row stride
-    const long n = (long)B * H * (W / SX) * (C / e);
-    const int nvg = (C / e + 7) / 8;
+    const long n = (long)B * H * (W / SX) * (C / 4);
+    const int nvg = (C / 4 + 7) / 8;
     int NSTRIP = 8;                                // strips per thread: fewer on small layers so that >= ~1000 blocks are in flight
     while (NSTRIP > 1 && ((((long)B * H * (W / SX) + NSTRIP - 1) / NSTRIP + 31) / 32) * nvg < 1024) NSTRIP >>= 1;
     const long nsg = (((long)B * H * (W / SX) + NSTRIP - 1) / NSTRIP + 31) / 32;

@@ -204,22 +204,24 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
     }
 }
 
-// weight / bias gradient.  block = 32 strip-groups x 8 channel vectors; a thread walks NSTRIP consecutive strips with its
-// 10 x E partial sums in registers; partials are reduced over the block (shuffles + LDS) before ONE atomic per word.
+// weight / bias gradient.  block = 8 strip lanes x 32 channel vectors (4 channels each: 256 contiguous bytes per pixel); a thread
+// walks NSTRIP consecutive strips with its 10 x 4 partial sums in registers; partials are folded over the block (one shuffle +
+// LDS) before ONE atomic per word.  Loads are branch-free (clamped coordinates, zeroed by select) so they issue back to back.
+constexpr int WG_VL = 32, WG_SL = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dh2, long ldg, const T* __restrict__ g1, long ld1,
                                                            float* __restrict__ dw, float* __restrict__ dbias, int B, int H, int W, int C, int NSTRIP) {
     constexpr int E = 4;                                   // channels per thread
-    __shared__ float red[8 * E * 10];
+    __shared__ float red[WG_VL * E * 10];
     const int nv = C / E, ns = W / SX;
-    const int nvg = (nv + 7) / 8;
+    const int nvg = (nv + WG_VL - 1) / WG_VL;
     const long nstrips = (long)B * H * ns;
-    const int vl = threadIdx.x & 7, sl = threadIdx.x >> 3;
-    const int v = (blockIdx.x % nvg) * 8 + vl;
-    const long s0 = ((long)(blockIdx.x / nvg) * 32 + sl) * NSTRIP;
+    const int vl = threadIdx.x & (WG_VL - 1), sl = threadIdx.x / WG_VL;
+    const int v = (blockIdx.x % nvg) * WG_VL + vl;
+    const long s0 = ((long)(blockIdx.x / nvg) * WG_SL + sl) * NSTRIP;
     const bool live = v < nv;
     const int c0 = (live ? v : 0) * E;
-    for (int i = threadIdx.x; i < 8 * E * 10; i += 256) red[i] = 0.f;
+    for (int i = threadIdx.x; i < WG_VL * E * 10; i += 256) red[i] = 0.f;
     float gw[10][E];
 #pragma unroll
     for (int k = 0; k < 10; ++k)
@@ -227,27 +229,40 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
         for (int e = 0; e < E; ++e) gw[k][e] = 0.f;
     if (live)
         for (long s = s0; s < nstrips && s < s0 + NSTRIP; ++s) {
-            const int y = (int)(s % H); const int sx = (int)((s / H) % ns); const long b = s / ((long)ns * H);      // walk down a column
+            const int sx = (int)(s % ns); const int y = (int)((s / ns) % H); const long b = s / ((long)ns * H);
             const int x0 = sx * SX;
-            float d[SX][E];
+            const bool left_ok = x0 > 0, right_ok = x0 + SX < W;
+            const int xl = left_ok ? x0 - 1 : 0, xr = right_ok ? x0 + SX : W - 1;
+            Raw4<T> rd[SX], raw[3][SX + 2];
             const T* drow = dh2 + ((b * H + y) * W + x0) * ldg + c0;
 #pragma unroll
+            for (int o = 0; o < SX; ++o) rd[o].load(drow + (long)o * ldg);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                int yy = y + ky - 1;
+                yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+                const T* row = g1 + ((b * H + yy) * W) * ld1 + c0;
+                raw[ky][0].load(row + (long)xl * ld1);
+#pragma unroll
+                for (int cx = 0; cx < SX; ++cx) raw[ky][cx + 1].load(row + (long)(x0 + cx) * ld1);
+                raw[ky][SX + 1].load(row + (long)xr * ld1);
+            }
+            float d[SX][E];
+#pragma unroll
             for (int o = 0; o < SX; ++o) {
-                ldvec4<T>(drow + (long)o * ldg, d[o]);
+                rd[o].unpack(d[o]);
 #pragma unroll
                 for (int e = 0; e < E; ++e) gw[9][e] += d[o][e];
             }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const int yy = y + ky - 1;
-                if (yy < 0 || yy >= H) continue;
-                const T* row = g1 + ((b * H + yy) * W) * ld1 + c0;
+                const bool row_ok = (y + ky - 1 >= 0) && (y + ky - 1 < H);
 #pragma unroll
                 for (int cx = -1; cx <= SX; ++cx) {
-                    const int xx = x0 + cx;
-                    if (xx < 0 || xx >= W) continue;
+                    Raw4<T> r = raw[ky][cx + 1];
+                    r.zero_unless(row_ok && (cx >= 0 || left_ok) && (cx < SX || right_ok));
                     float f[E];
-                    ldvec4<T>(row + (long)xx * ld1, f);
+                    r.unpack(f);
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int o = cx - kx + 1;
@@ -264,14 +279,14 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
     for (int k = 0; k < 10; ++k)
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            float s = gw[k][e];
-            s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-            if ((threadIdx.x & 63) < 8) atomicAdd(&red[(vl * E + e) * 10 + k], s);
+            float sum = gw[k][e];
+            sum += __shfl_xor(sum, 32, 64);                 // the wave's two strip lanes
+            if ((threadIdx.x & 63) < WG_VL) atomicAdd(&red[(vl * E + e) * 10 + k], sum);
         }
     __syncthreads();
-    for (int i = threadIdx.x; i < 8 * E * 10; i += 256) {
+    for (int i = threadIdx.x; i < WG_VL * E * 10; i += 256) {
         const int k = i % 10, ce = i / 10;
-        const int c = (blockIdx.x % nvg) * 8 * E + ce;
+        const int c = (blockIdx.x % nvg) * WG_VL * E + ce;
         if (c < C) {
             if (k < 9) atomicAdd(dw + (long)c * 9 + k, red[i]);                       // the parameter's own [C][3][3] layout
             else atomicAdd(dbias + c, red[i]);
@@ -770,10 +785,11 @@ extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g
     FW_CHECK_ARG(dh2 && g1 && h1 && w && dh1 && dw && dbias && C % e == 0 && ld1 % e == 0 && ldg % e == 0 && ldo % e == 0 && W % SX == 0);
     FW_CHECK_ARG(ldg == ld1);                      // the data-gradient strip kernel walks dh2 and h1 with one row stride
     const long n = (long)B * H * (W / SX) * (C / 4);
-    const int nvg = (C / 4 + 7) / 8;
-    int NSTRIP = 8;                                // strips per thread: fewer on small layers so that >= ~1000 blocks are in flight
-    while (NSTRIP > 1 && ((((long)B * H * (W / SX) + NSTRIP - 1) / NSTRIP + 31) / 32) * nvg < 1024) NSTRIP >>= 1;
-    const long nsg = (((long)B * H * (W / SX) + NSTRIP - 1) / NSTRIP + 31) / 32;
+    const int nvg = (C / 4 + WG_VL - 1) / WG_VL;
+    const long nst = (long)B * H * (W / SX);
+    int NSTRIP = 16;                               // strips per thread: fewer on small layers so that >= ~1000 blocks are in flight
+    while (NSTRIP > 2 && ((nst + (long)NSTRIP * WG_SL - 1) / ((long)NSTRIP * WG_SL)) * nvg < 768) NSTRIP >>= 1;   // every block ends in 1280 atomics: not too many blocks
+    const long nsg = (nst + (long)NSTRIP * WG_SL - 1) / ((long)NSTRIP * WG_SL);
     const dim3 gridw((unsigned)(nsg * nvg));
     if (dtype == FW_DT_BF16) {
         hipLaunchKernelGGL((dwconv_strip_kernel<bf16raw, 1>), dim3((grid_for(n) + 7) / 8 * 8), dim3(TPB), 0, ST, (const bf16raw*)dh2, ldg, w, (const float*)nullptr,

@@ -54,23 +54,39 @@ template <typename T> FW_DEV uint4 apply_gelu16(const uint4& v) {
 }
 
 // ---- epilogue of one lane: 4 consecutive n of row m ------------------------------------------
+// Two phases so that the loads of SEVERAL quads are in flight together: epi_fetch issues the operand loads of a quad from
+// clamped coordinates under wave-uniform conditions only (no lane-varying branch, nothing consumes the result yet);
+// epi_apply does the arithmetic and the stores and is the only part called under the lane's validity test.
+// ext carries ONE row-dependent operand of the quad: GELU'(aux) input when act == 2, else the f32 residual (when both are
+// given -- not in this model -- the residual is read inside epi_apply).  The bias depends on n only: fetched once per column.
 template <typename T>
-FW_DEV void epi_quad(const GemmArgs& a, const f32x4& acc, int m, int n0, float rs, int z) {
+FW_DEV void epi_fetch(const GemmArgs& a, uint4& ext, int mc, int nc, int z) {
+    if (a.act == 2) {
+        const T* ap = reinterpret_cast<const T*>(a.aux) + (long)mc * a.ldaux + nc;
+        if (sizeof(T) == 4) ext = *reinterpret_cast<const uint4*>(ap);
+        else { const uint2 t = *reinterpret_cast<const uint2*>(ap); ext.x = t.x; ext.y = t.y; }
+    } else if (a.residual && z == 0) {
+        ext = *reinterpret_cast<const uint4*>(a.residual + (long)mc * a.ldr + nc);
+    }
+}
+FW_DEV f32x4 epi_bias(const GemmArgs& a, int nc, int z) {
+    return (a.bias && z == 0) ? *reinterpret_cast<const f32x4*>(a.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+template <typename T>
+FW_DEV void epi_apply(const GemmArgs& a, const f32x4& bias, const uint4& ext, const f32x4& acc, int m, int n0, float rs, int z) {
     float v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = acc[r] * a.alpha;
-    if (a.bias && z == 0) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += b[r];
-    }
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] * a.alpha + bias[r];
     if (a.act == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = lrelu_f(v[r], a.slope);
     } else if (a.act == 2) {
-        const T* ap = reinterpret_cast<const T*>(a.aux) + (long)m * a.ldaux + n0;
+        float x[4];
+        if (sizeof(T) == 4) { x[0] = __uint_as_float(ext.x); x[1] = __uint_as_float(ext.y); x[2] = __uint_as_float(ext.z); x[3] = __uint_as_float(ext.w); }
+        else { x[0] = __uint_as_float(ext.x << 16); x[1] = __uint_as_float(ext.x & 0xffff0000u);
+               x[2] = __uint_as_float(ext.y << 16); x[3] = __uint_as_float(ext.y & 0xffff0000u); }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(TT<T>::ld(ap + r));
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(x[r]);
     } else if (a.act == 3) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
@@ -80,9 +96,9 @@ FW_DEV void epi_quad(const GemmArgs& a, const f32x4& acc, int m, int n0, float r
         for (int r = 0; r < 4; ++r) v[r] *= rs;
     }
     if (a.residual && z == 0) {
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(a.residual + (long)m * a.ldr + n0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += rr[r];
+        uint4 rr = ext;
+        if (a.act == 2) rr = *reinterpret_cast<const uint4*>(a.residual + (long)m * a.ldr + n0);
+        v[0] += __uint_as_float(rr.x); v[1] += __uint_as_float(rr.y); v[2] += __uint_as_float(rr.z); v[3] += __uint_as_float(rr.w);
     }
     if (a.C2) {
         T* c2 = reinterpret_cast<T*>(a.C2) + (long)m * a.ldc2 + n0;
@@ -93,8 +109,13 @@ FW_DEV void epi_quad(const GemmArgs& a, const f32x4& acc, int m, int n0, float r
     if (a.out_f32) {
         float* cp = reinterpret_cast<float*>(a.C) + (long)z * a.c_zstride + (long)m * a.ldc + n0;
         if (a.accumulate && a.c_zstride == 0) {
+            if (a.splitk == 1) {                        // every element has exactly one producer in this launch: plain 16-byte read-modify-write
+                const f32x4 old = *reinterpret_cast<const f32x4*>(cp);
+                *reinterpret_cast<f32x4*>(cp) = f32x4{old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
+                for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
+            }
         } else {
             *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
         }
@@ -111,24 +132,26 @@ template <typename T, int ROWS>
 struct StageDirect {
     static constexpr int NL = ROWS / 32;
     uint4 r[NL];
+    // Branch-free and two-phase: a load under a lane-varying branch (or followed at once by code that touches its destination)
+    // makes the wave wait for it before the next load is issued -- a chain of memory latencies per K step.  All loads are issued
+    // first, from clamped coordinates; out-of-range data is zeroed by selects afterwards.
     FW_MEM void load(const char* base, long ld, int row0, int rows_total, int kbyte0, int kbytes_end, int op) {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int t = 0; t < NL; ++t) {
             const int cid = tid + 256 * t;
-            const int row = cid >> 3, ch = cid & 7;
-            const int kb = kbyte0 + ch * 16;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row0 + row < rows_total && kb < kbytes_end) {
-                v = *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * ld * TT<T>::SZ + kb);
-                if (op == 1) v = apply_gelu16<T>(v);
-                const int valid = kbytes_end - kb;          // K*sizeof(T) need only be a multiple of 4 bytes
-                if (valid < 16) {
-                    if (valid <= 12) v.w = 0;
-                    if (valid <= 8) v.z = 0;
-                    if (valid <= 4) v.y = 0;
-                }
-            }
+            const int row = cid >> 3, kb = kbyte0 + (cid & 7) * 16;
+            const int rr = row0 + row < rows_total ? row0 + row : rows_total - 1;
+            r[t] = *reinterpret_cast<const uint4*>(base + (long)rr * ld * TT<T>::SZ + (kb < kbytes_end ? kb : 0));
+        }
+#pragma unroll
+        for (int t = 0; t < NL; ++t) {
+            const int cid = tid + 256 * t;
+            const int row = cid >> 3, kb = kbyte0 + (cid & 7) * 16;
+            uint4 v = r[t];
+            if (op == 1) v = apply_gelu16<T>(v);
+            const int valid = row0 + row < rows_total ? kbytes_end - kb : 0;     // K*sizeof(T) need only be a multiple of 4 bytes
+            v.x = valid > 0 ? v.x : 0u; v.y = valid > 4 ? v.y : 0u; v.z = valid > 8 ? v.z : 0u; v.w = valid > 12 ? v.w : 0u;
             r[t] = v;
         }
     }
@@ -158,7 +181,7 @@ struct StageTrans {
         for (int kk = 0; kk < 4; ++kk) {
             const int k = k0 + kb * 4 + kk;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (tid < NTHR && k < k_end && row0 + ib * E < rows_total) {
+            if (tid < NTHR && k < k_end && row0 + ib * E < rows_total) {         // nothing below touches v before the loop ends: the 4 loads stay in flight together
                 v = *reinterpret_cast<const uint4*>(base + ((long)k * ld + row0 + ib * E) * TT<T>::SZ);
                 if (op == 1) v = apply_gelu16<T>(v);
             }
@@ -340,16 +363,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     // ---- epilogue: lane holds C[m][n0..n0+3], m = col of the MFMA tile, n = rows -------------
     // (an LDS-staged, row-coalesced form of these stores measured ~20 % slower on MI355X: L2 merges the 8-byte pieces)
     const int l = lane_id();
+    f32x4 bias4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+        bias4[nt] = epi_bias(a, n0 < a.N ? n0 : 0, bz);
+    }
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt) {
         const int m = m_blk + wm0 + mt * 16 + (l & 15);
-        if (m >= a.M) continue;
-        const float rs = a.rowscale ? a.rowscale[m / a.rows_per_scale] : 1.0f;
+        const int mc = m < a.M ? m : a.M - 1;
+        const float rs = a.rowscale ? a.rowscale[mc / a.rows_per_scale] : 1.0f;
+        uint4 ext[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
-            if (n0 >= a.N) continue;
-            epi_quad<T>(a, acc[nt][mt], m, n0, rs, bz);
+            epi_fetch<T>(a, ext[nt], mc, n0 < a.N ? n0 : 0, bz);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+            if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], ext[nt], acc[nt][mt], m, n0, rs, bz);
         }
     }
 }
@@ -363,8 +397,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 //     memory into registers (16 B per lane, k-contiguous rows -- no LDS, no barrier), X is read exactly once for
 //     all columns of the panel, and the strip after next is requested before the epilogue of the current one.
 // 2 workgroups = 16 independent waves per CU keep loads, MFMAs and stores of different strips in flight together.
-template <typename T, int NCH, bool WT>
-__global__ __launch_bounds__(512, 2) void gemm_stream_kernel(GemmArgs a, int bnp) {
+template <typename T, int NCH, bool WT, bool EXT>
+__global__ __launch_bounds__(512, 2) void gemm_stream_kernel(GemmArgs a, int bnp) {   // 2nd argument: waves per SIMD (2 workgroups per CU = 4)
     constexpr int SZ = TT<T>::SZ, E = TT<T>::E16;
     constexpr int RL = NCH * 64;                          // bytes of K per LDS row (NCH even: whole 128-byte swizzle groups)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -431,37 +465,41 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(GemmArgs a, int bnp
     const int ncols = min(bnp, a.N - n_blk);
     const int nnb = (ncols + 63) >> 6;
     uint4 xf[2][NCH];
-    auto load_x = [&](int strip) {
+    auto issue_x = [&](int strip) {                       // phase 1: the loads only (clamped coordinates), see StageDirect::load
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int row = strip * 32 + mt * 16 + (l & 15);
-            const char* src = a.X + (long)row * a.ldx * SZ + ((l >> 4) << 4);
+            const char* src = a.X + (long)(row < a.M ? row : a.M - 1) * a.ldx * SZ;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int kb = c * 64 + ((l >> 4) << 4);
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (row < a.M && kb < kbytes) {
-                    v = *reinterpret_cast<const uint4*>(src + c * 64);
-                    const int valid = kbytes - kb;
-                    if (valid < 16) {
-                        if (valid <= 12) v.w = 0;
-                        if (valid <= 8) v.z = 0;
-                        if (valid <= 4) v.y = 0;
-                    }
-                }
+                xf[mt][c] = *reinterpret_cast<const uint4*>(src + (kb < kbytes ? kb : 0));
+            }
+        }
+    };
+    auto mask_x = [&](int strip) {                        // phase 2: zero what lies past M / K
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const bool rok = strip * 32 + mt * 16 + (l & 15) < a.M;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int valid = rok ? kbytes - (c * 64 + ((l >> 4) << 4)) : 0;
+                uint4 v = xf[mt][c];
+                v.x = valid > 0 ? v.x : 0u; v.y = valid > 4 ? v.y : 0u; v.z = valid > 8 ? v.z : 0u; v.w = valid > 12 ? v.w : 0u;
                 xf[mt][c] = v;
             }
         }
     };
     int strip = blockIdx.x * 8 + wave;
-    if (strip < strips) load_x(strip);
+    if (strip < strips) issue_x(strip);
     for (; strip < strips; strip += stride) {
+        mask_x(strip);
         const int m_lane = strip * 32 + (l & 15);
         float rs[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int m = m_lane + mt * 16;
-            rs[mt] = (a.rowscale && m < a.M) ? a.rowscale[m / a.rows_per_scale] : 1.0f;
+            rs[mt] = a.rowscale ? a.rowscale[(m < a.M ? m : a.M - 1) / a.rows_per_scale] : 1.0f;
         }
 #pragma unroll 1
         for (int nb = 0; nb < nnb; ++nb) {
@@ -481,23 +519,32 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(GemmArgs a, int bnp
                     mma_chunk<T>(acc[i][1], af[i], xf[1][c]);
                 }
             }
-            if (nb == nnb - 1 && strip + stride < strips) load_x(strip + stride);   // request the next strip, then write this one out
+            if (nb == nnb - 1 && strip + stride < strips) issue_x(strip + stride);   // request the next strip, then write this one out
+            // EXT (a row-dependent operand: GELU' input or residual): the 4 quads of 16 rows are fetched together before they are
+            // applied; otherwise quad by quad, which keeps the kernel at 4 waves per SIMD
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int m = m_lane + mt * 16;
-                if (m >= a.M) continue;
+                const int mc = m < a.M ? m : a.M - 1;
+                uint4 ext[4];
+                if constexpr (EXT) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int n0 = n_blk + nb * 64 + i * 16 + ((l >> 4) << 2);
+                        epi_fetch<T>(a, ext[i], mc, n0 < a.N ? n0 : 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int n0 = n_blk + nb * 64 + i * 16 + ((l >> 4) << 2);
-                    if (n0 >= a.N) continue;
-                    epi_quad<T>(a, acc[i][mt], m, n0, rs[mt], 0);
+                    if (m < a.M && n0 < a.N) epi_apply<T>(a, epi_bias(a, n0, 0), ext[i], acc[i][mt], m, n0, rs[mt], 0);
                 }
             }
         }
     }
 }
 
-template <typename T, int NCH, bool WT>
+template <typename T, int NCH, bool WT, bool EXT>
 int launch_stream(const GemmArgs& a, hipStream_t st) {
     constexpr int RL = NCH * 64;
     const int maxb = ((64 * 1024) / RL) & ~63;                      // panel columns that fit 64 KB (2 workgroups per CU)
@@ -506,23 +553,29 @@ int launch_stream(const GemmArgs& a, hipStream_t st) {
     const size_t lds = (size_t)bnp * RL;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<T, NCH, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<T, NCH, WT, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_done = true;
     }
     const int strips = fw_cdiv(a.M, 32);
     int gx = fw_cdiv(strips, 8);
     const int cap = 512 / ny > 0 ? 512 / ny : 1;                    // 256 CUs x 2 workgroups
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL((gemm_stream_kernel<T, NCH, WT>), dim3(gx, ny), dim3(512), lds, st, a, bnp);
+    hipLaunchKernelGGL((gemm_stream_kernel<T, NCH, WT, EXT>), dim3(gx, ny), dim3(512), lds, st, a, bnp);
     FW_LAUNCH_RET();
 }
 
+template <typename T, int NCH>
+int dispatch_stream_n(const GemmArgs& a, int wt, hipStream_t st) {
+    const bool ext = a.act == 2 || a.residual != nullptr;           // a row-dependent epilogue operand is prefetched (more registers)
+    if (wt) return ext ? launch_stream<T, NCH, true, true>(a, st) : launch_stream<T, NCH, true, false>(a, st);
+    return ext ? launch_stream<T, NCH, false, true>(a, st) : launch_stream<T, NCH, false, false>(a, st);
+}
 template <typename T>
 int dispatch_stream(const GemmArgs& a, int wt, hipStream_t st) {
     const int nch = fw_cdiv(a.K * TT<T>::SZ, 128) * 2;
-    if (nch <= 2) return wt ? launch_stream<T, 2, true>(a, st) : launch_stream<T, 2, false>(a, st);
-    if (nch <= 4) return wt ? launch_stream<T, 4, true>(a, st) : launch_stream<T, 4, false>(a, st);
-    return wt ? launch_stream<T, 8, true>(a, st) : launch_stream<T, 8, false>(a, st);
+    if (nch <= 2) return dispatch_stream_n<T, 2>(a, wt, st);
+    if (nch <= 4) return dispatch_stream_n<T, 4>(a, wt, st);
+    return dispatch_stream_n<T, 8>(a, wt, st);
 }
 
 template <typename T, int BN, bool XT, bool WT, bool GX, bool GW>

@@ -110,22 +110,34 @@ FW_DEV void wave_fence() {
 }
 
 // Copy the 64 window rows of one head ([64][D]) global -> LDS tile (zero padded to whole chunks); whole workgroup.
-template <typename T, int D>
-FW_DEV void load_tile(char* tile, const char* base, long ld, int n, int wy, int wx, int H, int W, int shift, int col) {
+// Two phases: issue() only loads (clamped coordinates, no lane-varying branch, nothing consumes the data), commit() zero-pads
+// and writes LDS -- so the loads of SEVERAL tiles (Q, K, V, dO) are in flight together instead of one memory latency each.
+template <typename T, int D> struct TileLoad {
     using G = Geo<T, D>;
-    for (int idx = threadIdx.x; idx < 64 * G::SL; idx += NTH) {
-        const int t = idx / G::SL, s = idx % G::SL;
-        if (G::CB == 16) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (s < G::CH) v = *reinterpret_cast<const uint4*>(base + (token_row(n, wy, wx, t, H, W, shift) * ld + col) * G::SZ + s * 16);
-            *reinterpret_cast<uint4*>(tile + t * G::LDR + s * 16) = v;
-        } else {
-            uint2 v = make_uint2(0, 0);
-            if (s < G::CH) v = *reinterpret_cast<const uint2*>(base + (token_row(n, wy, wx, t, H, W, shift) * ld + col) * G::SZ + s * 8);
-            *reinterpret_cast<uint2*>(tile + t * G::LDR + s * 8) = v;
+    static constexpr int NI = (64 * G::SL + NTH - 1) / NTH;
+    uint4 r[NI];
+    FW_MEM void issue(const char* base, long ld, int n, int wy, int wx, int H, int W, int shift, int col) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = threadIdx.x + i * NTH;
+            const int t = (idx / G::SL) & 63, s = idx % G::SL;
+            const char* p = base + (token_row(n, wy, wx, t, H, W, shift) * ld + col) * G::SZ + (s < G::CH ? s : 0) * G::CB;
+            if (G::CB == 16) r[i] = *reinterpret_cast<const uint4*>(p);
+            else { const uint2 v = *reinterpret_cast<const uint2*>(p); r[i].x = v.x; r[i].y = v.y; }
         }
     }
-}
+    FW_MEM void commit(char* tile) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = threadIdx.x + i * NTH;
+            if (idx >= 64 * G::SL) continue;
+            const int t = idx / G::SL, s = idx % G::SL;
+            const bool ok = s < G::CH;
+            if (G::CB == 16) *reinterpret_cast<uint4*>(tile + t * G::LDR + s * 16) = ok ? r[i] : make_uint4(0, 0, 0, 0);
+            else *reinterpret_cast<uint2*>(tile + t * G::LDR + s * 8) = ok ? make_uint2(r[i].x, r[i].y) : make_uint2(0, 0);
+        }
+    }
+};
 // Copy rows r0..r0+15 of a [64][D] LDS tile -> the matching window rows of one head; ONE wave (its own strip).
 template <typename T, int D>
 FW_DEV void store_rows16(const char* tile, char* base, long ld, int n, int wy, int wx, int H, int W, int shift, int col, int r0) {
@@ -298,12 +310,18 @@ __global__ __launch_bounds__(NTH, 3) void attn_fwd_kernel(AttnArgs a) {
         const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
         const bool last_y = wy == nWy - 1, last_x = wx == nWx - 1;
         const int nq = lq * a.B + b;
-        load_tile<T, D>(rA, a.q, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
+        {
+            TileLoad<T, D> tq, tk[NKT], tv[NKT];
+            tq.issue(a.q, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            const int lk = a.mode == 0 ? lq : other_band(lq, kt);
-            load_tile<T, D>(rB + kt * S::RB, a.k, a.ld, lk * a.B + b, wy, wx, a.H, a.W, a.shift, h * D);
-            load_tile<T, D>(rV + kt * G::TILE_D, a.v, a.ld, lk * a.B + b, wy, wx, a.H, a.W, a.shift, h * D);
+            for (int kt = 0; kt < NKT; ++kt) {
+                const int lk = a.mode == 0 ? lq : other_band(lq, kt);
+                tk[kt].issue(a.k, a.ld, lk * a.B + b, wy, wx, a.H, a.W, a.shift, h * D);
+                tv[kt].issue(a.v, a.ld, lk * a.B + b, wy, wx, a.H, a.W, a.shift, h * D);
+            }
+            tq.commit(rA);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) { tk[kt].commit(rB + kt * S::RB); tv[kt].commit(rV + kt * G::TILE_D); }
         }
         __syncthreads();
         // S^T[j][i] = sum_d K[j][d] Q[i][d], own columns i
@@ -418,8 +436,9 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_kernel(AttnArgs a) {
         const bool last_y = wy == nWy - 1, last_x = wx == nWx - 1;
         const int nq = lq * a.B + b;
         const size_t item = ((size_t)win * a.L + lq) * a.heads + h;
-        load_tile<T, D>(sQ, a.q, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
-        load_tile<T, D>(sDO, a.dout, a.lddo, nq, wy, wx, a.H, a.W, a.shift, h * D);
+        TileLoad<T, D> tq, tdo;
+        tq.issue(a.q, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
+        tdo.issue(a.dout, a.lddo, nq, wy, wx, a.H, a.W, a.shift, h * D);
         const float lse = a.lse[item * 64 + i];
         float di = 0.f;
         if constexpr (NKT > 1) {
@@ -439,9 +458,14 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_kernel(AttnArgs a) {
             const int lk = a.mode == 0 ? lq : other_band(lq, kt);
             const int nk = lk * a.B + b;
             const int tabid = lq * a.L + lk;
-            __syncthreads();                                 // every wave is done with the previous K / V tiles and scratch
-            load_tile<T, D>(sK, a.k, a.ld, nk, wy, wx, a.H, a.W, a.shift, h * D);
-            load_tile<T, D>(sV, a.v, a.ld, nk, wy, wx, a.H, a.W, a.shift, h * D);
+            {
+                TileLoad<T, D> tk, tv;
+                tk.issue(a.k, a.ld, nk, wy, wx, a.H, a.W, a.shift, h * D);
+                tv.issue(a.v, a.ld, nk, wy, wx, a.H, a.W, a.shift, h * D);
+                __syncthreads();                             // every wave is done with the previous K / V tiles and scratch
+                if (kt == 0) { tq.commit(sQ); tdo.commit(sDO); }
+                tk.commit(sK); tv.commit(sV);
+            }
             __syncthreads();
             // P^T[j][i] = exp(scale * K Q^T + bias + mask - lse_i), own columns i
             f32x4 p[4], dp[4];

@@ -163,6 +163,18 @@ def gemm_profile(engine, batch, reps=8):
     return agg, len(rec)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2 -- the gfx950
+    correction of MI355X_MICROARCH.md -- plus WRITE_SIZE, two separate --pmc runs of this same bench command; summarised by
+    tools/pmc_summary.py).  None when no measurement for this kernel is on file."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(threads):
     """The CPU oracle (oracle/airnet_oracle.py, the fp32 restatement pinned against the reference) timed on the host
     cores: phase-2 steps (forward + backward + Adam) at B = 2, 128x128 -- a bounded sample of the same workload."""
@@ -267,6 +279,15 @@ def main():
     loss = [float(v) for v in out]
     ips = args.batch * world * args.steps / dt
     log(f'{ips:.1f} images/sec, {dt / args.steps * 1e3:.1f} ms/step')
+    # what the rate would be if every step also took its batch over PCIe (pinned host -> HBM, not overlapped): reported, never `value`
+    host = [t.cpu().pin_memory() for t in (xq, xk, clean)]
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        for h, d in zip(host, (xq, xk, clean)):
+            d.copy_(h, non_blocking=True)
+    torch.cuda.synchronize()
+    h2d = (time.perf_counter() - t1) / 5
 
     res = {
         'metric': 'training images/sec @128x128', 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
@@ -276,6 +297,7 @@ def main():
                                '128x128, phase-2 train step (fwd+bwd+Adam, DropPath on)', 'per_gpu_batch': args.batch,
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'hip_graph': graph_ok},
         'loss': {'total': loss[0], 'l1': loss[1], 'contrast': loss[2]},
+        'pcie_inclusive_value': round(args.batch * world / (dt / args.steps + h2d), 2), 'h2d_ms_per_step': round(h2d * 1e3, 3),
     }
     peak = PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32_MFMA
     res['step_mfma_fraction'] = round(ips / world * FLOP_PER_IMAGE_STEP / peak, 5)
@@ -288,11 +310,11 @@ def main():
         # the variant's launches are priced one by one against max(FLOPs / MFMA peak, bytes / HBM peak); `bound` is the
         # side that sets most of that time, `achieved` / `peak` are quoted in its unit, `frac` = roofline time / measured
         hbm = by / PEAK_HBM > fl / peak
-        res['roofline'] = {'bound': 'hbm' if hbm else 'mfma',
-                           'kernel': (f'gemm_stream_kernel<{v[0]},wT={int(v[3])}>' if v[1] == 'stream' else f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>'),
+        kname = f'gemm_stream_kernel<{v[0]},wT={int(v[3])}>' if v[1] == 'stream' else f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>'
+        res['roofline'] = {'bound': 'hbm' if hbm else 'mfma', 'kernel': kname,
                            'achieved': round((by / tt / 1e9) if hbm else (fl / tt / 1e12), 2),
                            'peak': (PEAK_HBM / 1e9) if hbm else (peak / 1e12), 'unit': 'GB/s' if hbm else 'TFLOP/s',
-                           'frac': round(troof / tt, 5), 'traffic': None, 'avg_launch_us': round(tt / cnt * 1e6, 2),
+                           'frac': round(troof / tt, 5), 'traffic': pmc_traffic(kname), 'avg_launch_us': round(tt / cnt * 1e6, 2),
                            'tflops': round(fl / tt / 1e12, 2), 'algorithmic_gbs': round(by / tt / 1e9, 1),
                            'launches_per_step': cnt, 'gemm_launches_per_step': launches,
                            'gemm_time_ms_per_step': round(tot_t * 1e3, 3),

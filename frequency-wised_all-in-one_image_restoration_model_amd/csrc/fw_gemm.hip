@@ -278,16 +278,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     auto ws = [&](int i) -> char* { return smem + i * (XBYTES + WBYTES) + XBYTES; };
 
     const int wave = threadIdx.x >> 6;
-    // Workgroups are dealt round-robin to the 8 XCDs (8 private L2s).  With split-K every output tile of one K slice reads the
-    // same token rows: keep a slice's tiles on ONE XCD (slices z = xcd, xcd + 8, ...) so its operands are fetched into one L2
-    // instead of eight.  (Without split-K, tiles sharing X rows are gridDim.x apart and already meet when gridDim.x % 8 == 0.)
+    // Workgroups are dealt round-robin to the 8 XCDs (8 private L2s).  With split-K the tiles of one K slice read the same token
+    // rows: give every XCD one CONTIGUOUS eighth of the (slice, n tile, m tile) order, so that a slice's operands are fetched into
+    // one or two L2s instead of all eight (PMC: 1.9x the algorithmic bytes crossed the fabric with round-robin placement).
+    // (Without split-K, tiles sharing X rows are gridDim.x apart and already meet when gridDim.x % 8 == 0.)
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (gridDim.z >= 8 && (gridDim.z & 7) == 0) {
-        const unsigned nt = gridDim.x * gridDim.y;
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const unsigned r = lin >> 3, t = r % nt;
-        bz = (int)((r / nt) * 8 + (lin & 7));
-        bx = (int)(t % gridDim.x); by = (int)(t / gridDim.x);
+    {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        if (gridDim.z > 1 && (total & 7) == 0) {
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            bx = (int)(w % gridDim.x);
+            by = (int)((w / gridDim.x) % gridDim.y);
+            bz = (int)(w / (gridDim.x * gridDim.y));
+        }
     }
     const int m_blk = bx * BM, n_blk = by * BN;
     const int wm0 = (BN == 128) ? (wave & 1) * 64 : wave * 32;

@@ -37,8 +37,11 @@ def pick_splitk(M, N, K, dtype):
     MI355X (tools/splitk_sweep.py): about 512 blocks in flight, at least 512 reduction rows (8 K-steps) per block."""
     tiles = ((M + 127) // 128) * ((N + 63) // 64 if N <= 64 else (N + 127) // 128)
     sk = max(1, min(512 // max(tiles, 1), K // 512))
-    if sk >= 8:
-        sk -= sk % 8                                         # whole groups of 8 slices: fw_gemm keeps a slice's tiles on one XCD
+    if sk > 1 and (tiles * sk) % 8:                          # fw_gemm deals contiguous eighths of the tile order to the 8 XCDs
+        for cand in (sk + 1, sk - 1, sk + 2, sk + 3):
+            if cand > 1 and (tiles * cand) % 8 == 0 and K // cand >= 256:
+                sk = cand
+                break
     while sk > 1 and sk * M * N * 4 > (256 << 20):          # keep the partial-tile slab under 256 MB
         sk //= 2
     return int(sk)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py -> HBM bytes per launch of the GEMM kernels.
+
+    tools/pmc_summary.py <fetch_dir> <write_dir> <out.json>
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB-sized units of 1024 bytes by rocprofv3's derived counters; on gfx950 FETCH_SIZE
+tallies the 128-byte requests of wide coalesced reads at 64 bytes, so it is doubled (MI355X_MICROARCH.md, section HBM)."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for path in f:
+        for r in csv.DictReader(open(path)):
+            if r.get('Counter_Name') != counter:
+                continue
+            acc[r['Kernel_Name']][0] += float(r['Counter_Value'])
+            acc[r['Kernel_Name']][1] += 1
+    return acc
+
+
+def short(name):
+    m = re.search(r'gemm_(stream_)?kernel<([^>]*)>', name)
+    if not m:
+        return None
+    a = [x.strip() for x in m.group(2).split(',')]
+    dt = 'bf16' if a[0] == 'unsigned short' else 'f32'
+    if m.group(1):
+        return f'gemm_stream_kernel<{dt},wT={int(a[2] == "true")}>'
+    return f'gemm_kernel<{dt},BN={a[1]},xT={int(a[2] == "true")},wT={int(a[3] == "true")}>'
+
+
+fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
+out = {}
+agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
+for name, (v, n) in fetch.items():
+    k = short(name)
+    if k:
+        agg[k][0] += v; agg[k][2] += n
+for name, (v, n) in write.items():
+    k = short(name)
+    if k:
+        agg[k][1] += v
+for k, (fv, wv, n) in agg.items():
+    out[k] = {'launches': n, 'fetch_kib_raw_per_launch': fv / n, 'write_kib_per_launch': wv / n,
+              'hbm_bytes_per_launch': int((2.0 * fv + wv) * 1024 / n)}
+json.dump(out, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches']):
+    print(f"{k:45s} launches {v['launches']:6d}  HBM bytes/launch {v['hbm_bytes_per_launch'] / 1e6:9.2f} MB")

@@ -674,51 +674,57 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 // Many slabs in one launch (every weight-gradient / LayerNorm partial of a backward pass, folded once at its end).
-// tab: [num][10] int64 = slab, dst, dst2, n, zstride, off2, n2, nz, zper, gx;  prefix: [num + 1] int64 block offsets.
-// Every entry accumulates into dst / dst2 (atomics when its z range is split over several blocks).
+// tab: [num][12] int64 = slab, dst, dst2, n, zstride, off2, n2, nz, zper, nchunks, upw, (pad);  prefix: [num + 1] int64 block
+// offsets.  Work unit = (64 consecutive 16-byte columns, one z range of zper slab rows); a WAVE owns upw consecutive units and
+// sums each with 8 independent loads in flight -- no LDS, no barrier; the host sizes upw so that a wave moves >= ~32 KB.
+// Every entry accumulates into dst / dst2 with atomics (z-split entries; two entries may share a destination).
 __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const long long* __restrict__ tab, const long long* __restrict__ prefix, int num) {
-    __shared__ f32x4 red[3][64];
     int lo = 0, hi = num;                                  // entry e with prefix[e] <= blockIdx.x < prefix[e + 1]
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (prefix[mid] <= (long long)blockIdx.x) lo = mid; else hi = mid;
     }
-    const long long* t = tab + (long)lo * 10;
+    const long long* t = tab + (long)lo * 12;
     const float* slab = reinterpret_cast<const float*>(t[0]);
     float* dst = reinterpret_cast<float*>(t[1]);
     float* dst2 = reinterpret_cast<float*>(t[2]);
     const long n = t[3], zstride = t[4], off2 = t[5], n2 = t[6];
-    const int nz = (int)t[7], zper = (int)t[8], gx = (int)t[9];
-    const int local = (int)((long long)blockIdx.x - prefix[lo]);
-    const int bx = local % gx, by = local / gx;
-    const int lane = threadIdx.x & 63, zl = threadIdx.x >> 6;
-    const long i4 = (long)bx * 64 + lane;
+    const int nz = (int)t[7], zper = (int)t[8];
+    const long nchunks = t[9];
+    const int upw = (int)t[10];
+    const long splits = (nz + zper - 1) / zper, units = nchunks * splits;
+    const long gw = ((long long)blockIdx.x - prefix[lo]) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const long end = dst2 ? off2 + n2 : n;
-    const bool live = i4 * 4 < end;
-    const int z0 = by * zper, z1 = min(nz, z0 + zper);
-    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (live) {
+    for (long u = gw * upw; u < units && u < (gw + 1) * upw; ++u) {
+        const long c = u % nchunks; const int sp = (int)(u / nchunks);
+        const long i4 = c * 64 + lane;
+        if (i4 * 4 >= end) continue;
+        const int z0 = sp * zper, z1 = min(nz, z0 + zper);
         const float* p = slab + i4 * 4;
-        int z = z0 + zl;
-        for (; z + 12 < z1; z += 16) {
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        int z = z0;
+        for (; z + 7 < z1; z += 8) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (long)z * zstride);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + (long)(z + 4) * zstride);
-            const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (long)(z + 8) * zstride);
-            const f32x4 a3 = *reinterpret_cast<const f32x4*>(p + (long)(z + 12) * zstride);
-            s += (a0 + a1) + (a2 + a3);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + (long)(z + 1) * zstride);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (long)(z + 2) * zstride);
+            const f32x4 a3 = *reinterpret_cast<const f32x4*>(p + (long)(z + 3) * zstride);
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(p + (long)(z + 4) * zstride);
+            const f32x4 a5 = *reinterpret_cast<const f32x4*>(p + (long)(z + 5) * zstride);
+            const f32x4 a6 = *reinterpret_cast<const f32x4*>(p + (long)(z + 6) * zstride);
+            const f32x4 a7 = *reinterpret_cast<const f32x4*>(p + (long)(z + 7) * zstride);
+            s0 += (a0 + a1) + (a2 + a3);
+            s1 += (a4 + a5) + (a6 + a7);
         }
-        for (; z < z1; z += 4) s += *reinterpret_cast<const f32x4*>(p + (long)z * zstride);
-    }
-    if (zl > 0) red[zl - 1][lane] = s;
-    __syncthreads();
-    if (zl > 0 || !live) return;
-    s += red[0][lane] + red[1][lane] + red[2][lane];
-    for (int e = 0; e < 4; ++e) {
-        const long i = i4 * 4 + e;
-        float* d = nullptr;
-        if (i < n) d = dst + i;
-        else if (dst2 && i >= off2 && i < off2 + n2) d = dst2 + (i - off2);
-        if (d) atomicAdd(d, s[e]);       // always atomic: z-split entries, and two entries may share a destination (a weight used twice)
+        for (; z < z1; ++z) s0 += *reinterpret_cast<const f32x4*>(p + (long)z * zstride);   // rows are padded to 4
+        s0 += s1;
+        for (int e = 0; e < 4; ++e) {
+            const long i = i4 * 4 + e;
+            float* d = nullptr;
+            if (i < n) d = dst + i;
+            else if (dst2 && i >= off2 && i < off2 + n2) d = dst2 + (i - off2);
+            if (d) atomicAdd(d, s0[e]);
+        }
     }
 }
 __global__ void fill_kernel(float* __restrict__ p, long n, float v) {
@@ -923,8 +929,8 @@ extern "C" int fw_slab_reduce(const float* slab, int nz, long n, long zstride, f
     hipLaunchKernelGGL(slab_reduce_kernel, grid, dim3(256), 0, ST, slab, nz, n, zstride, dst, accumulate, zper, dst2, off2, n2);
     FW_LAUNCH_RET();
 }
-// One launch for `num` slabs.  tab / prefix are DEVICE arrays laid out as slab_reduce_multi_kernel documents (the host picks
-// zper and gx = ceil(ceil(max(n, off2 + n2) / 4) / 64) per entry; an entry owns gx * ceil(nz / zper) consecutive blocks).
+// One launch for `num` slabs.  tab / prefix are DEVICE arrays laid out as slab_reduce_multi_kernel documents (the host picks zper,
+// nchunks = ceil(ceil(max(n, off2 + n2) / 4) / 64) and upw per entry; an entry owns ceil(nchunks * ceil(nz / zper) / (4 * upw)) blocks).
 extern "C" int fw_slab_reduce_multi(const void* tab, const void* prefix, int num, long total_blocks, void* stream) {
     FW_CHECK_ARG(tab && prefix && num > 0 && total_blocks > 0 && total_blocks < (1L << 31));
     hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, ST, (const long long*)tab, (const long long*)prefix, num);

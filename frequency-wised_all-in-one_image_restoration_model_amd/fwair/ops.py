@@ -109,23 +109,25 @@ def flush_slabs():
     _pending.clear()
     num = len(items)
     dev = items[0][0].device
-    host = _host_table(num * 10 + num + 1)
-    tab, prefix = host[:num * 10].view(num, 10), host[num * 10:]
+    host = _host_table(num * 12 + num + 1)
+    tab, prefix = host[:num * 12].view(num, 12), host[num * 12:]
     rows, offs, total = [], [0], 0
     for slab, nz, n, zstride, dst, dst2, off2, n2 in items:
         end = off2 + n2 if dst2 is not None else n
-        gx = ((end + 3) // 4 + 63) // 64
-        splits = max(1, min(nz // 8, 1024 // gx))              # aim at ~1024 blocks per entry, >= 8 slab rows per block
-        zper = (nz + splits - 1) // splits
-        gy = (nz + zper - 1) // zper
-        rows.append((slab.data_ptr(), dst.data_ptr(), dst2.data_ptr() if dst2 is not None else 0, n, zstride, off2, n2, nz, zper, gx))
-        total += gx * gy
+        nchunks = ((end + 3) // 4 + 63) // 64                  # 64 lanes x 16 bytes
+        zper = min(nz, 64)
+        splits = (nz + zper - 1) // zper
+        upw = max(1, 32 // zper)                               # units per wave: >= ~32 KB moved by every wave
+        blocks = (nchunks * splits + 4 * upw - 1) // (4 * upw)
+        rows.append((slab.data_ptr(), dst.data_ptr(), dst2.data_ptr() if dst2 is not None else 0, n, zstride, off2, n2, nz, zper,
+                     nchunks, upw, 0))
+        total += blocks
         offs.append(total)
     tab.copy_(torch.tensor(rows, dtype=torch.int64))
     prefix.copy_(torch.tensor(offs, dtype=torch.int64))
     table = torch.empty(host.shape, dtype=torch.int64, device=dev)
     table.copy_(host, non_blocking=True)
-    call('fw_slab_reduce_multi', table, table[num * 10:], num, total)
+    call('fw_slab_reduce_multi', table, table[num * 12:], num, total)
     if not torch.cuda.is_current_stream_capturing():
         for slot in _host_ring:
             if slot[0].data_ptr() == host.data_ptr():

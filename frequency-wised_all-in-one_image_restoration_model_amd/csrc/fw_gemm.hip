@@ -393,6 +393,128 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 }
 
 // =====================================================================================================
+// Weight-gradient kernel, bf16:  C[m][n] = sum_t X[t][m] W[t][n]  (both operands token-major: dW = dY^T x).
+// The tile kernel above transposes both operands in registers while staging them (v_perm + 8-byte LDS writes every K step).
+// Here the token-major tiles go to LDS AS THEY ARE -- global_load_lds, no VGPR round trip, no VALU -- and the MFMA fragments,
+// which need 8 consecutive TOKENS per lane, are read with gfx950's transposing LDS read (ds_read_b64_tr_b16, two per
+// fragment).  LDS image: [64 tokens][128 columns] bf16 = 256-byte rows whose 16-byte chunks are XOR-swizzled by
+// f(row) = ((row & 3) << 2) | ((row >> 2) & 3)  (conflict-free for the transposed reads: cdna_hip_programming.md T10 image (b));
+// global_load_lds writes LDS lane-linearly, so the swizzle is applied to the per-lane SOURCE chunk.
+// The bias gradient (column sums of X) comes from MFMAs against an all-ones A fragment -- no extra pass over the data.
+FW_DEV int swz256(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+// one [64 tokens][128 cols] tile; wave w fills token rows 16w .. 16w+15 with 4 wave-instructions of 4 rows each
+FW_DEV void glds_issue_km(const char* base, long ld, int col0, int cols_total, int k0, char* tile) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int R0 = wave * 16 + it * 4;
+        const int r = R0 + (lane >> 4), p = lane & 15;
+        int col = col0 + ((p ^ swz256(r)) << 3);
+        if (col >= cols_total) col = 0;                    // columns past the matrix only feed masked outputs; stay inside the row
+        const char* g = base + ((long)(k0 + r) * ld + col) * 2;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)(tile + R0 * 256), 16, 0, 0);
+    }
+}
+// MFMA fragment of operand rows (= tile columns) m0 .. m0+15 over token chunk c (32 tokens): two transposing reads
+FW_DEV uint4 frag_tr256(const char* tile, int m0, int chunk) {
+    const int l = lane_id();
+    const int r = chunk * 32 + ((l >> 4) << 3) + ((l >> 2) & 3);
+    const int ch = (m0 >> 3) + ((l & 3) >> 1), sub = (l & 1) << 3;
+    const char* p0 = tile + 256 * r + ((ch ^ swz256(r)) << 4) + sub;
+    const char* p1 = tile + 256 * (r + 4) + ((ch ^ swz256(r + 4)) << 4) + sub;
+    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((fw_lds_s16x4*)p0));
+    const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((fw_lds_s16x4*)p1));
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs a) {
+    using T = bf16raw;
+    constexpr int KT = 64, WM = 4, TILE = 64 * 256;      // tokens per step, m tiles per wave, bytes per operand tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto xs = [&](int i) -> char* { return smem + i * 2 * TILE; };
+    auto ws = [&](int i) -> char* { return smem + i * 2 * TILE + TILE; };
+    const int wave = threadIdx.x >> 6;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {                                                     // contiguous eighths of the (slice, n tile, m tile) order per XCD, see gemm_kernel
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        if (gridDim.z > 1 && (total & 7) == 0) {
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            bx = (int)(w % gridDim.x);
+            by = (int)((w / gridDim.x) % gridDim.y);
+            bz = (int)(w / (gridDim.x * gridDim.y));
+        }
+    }
+    const int m_blk = bx * 128, n_blk = by * 128;
+    const int wm0 = (wave & 1) * 64, wn0 = (wave >> 1) * 64;
+    const int k_begin = bz * a.kper;
+    const int k_end = min(a.K, k_begin + a.kper);
+    const int nsteps = (k_end - k_begin) / KT;           // whole steps only (host guarantees K % 64 == 0)
+
+    f32x4 acc[4][WM], xsacc[WM];
+    zero_acc(acc);
+#pragma unroll
+    for (int m = 0; m < WM; ++m) xsacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_xsum = a.xsum != nullptr && by == 0 && wn0 == 0;          // wave-uniform
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // bf16 1.0 x 8
+
+    if (nsteps > 0) {
+        glds_issue_km(a.X, a.ldx, m_blk, a.M, k_begin, xs(0));
+        glds_issue_km(a.W, a.ldw, n_blk, a.N, k_begin, ws(0));
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nsteps) {
+            glds_issue_km(a.X, a.ldx, m_blk, a.M, k_begin + (s + 1) * KT, xs(cur ^ 1));
+            glds_issue_km(a.W, a.ldw, n_blk, a.N, k_begin + (s + 1) * KT, ws(cur ^ 1));
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint4 af[4], bfr[WM];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = frag_tr256(ws(cur), wn0 + 16 * m, c);
+#pragma unroll
+            for (int n = 0; n < WM; ++n) bfr[n] = frag_tr256(xs(cur), wm0 + 16 * n, c);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < WM; ++n) mma_chunk<T>(acc[m][n], af[m], bfr[n]);
+            if (do_xsum) {
+#pragma unroll
+                for (int n = 0; n < WM; ++n) mma_chunk<T>(xsacc[n], ones, bfr[n]);
+            }
+        }
+        __syncthreads();                                 // also drains the in-flight global_load_lds (vmcnt(0))
+    }
+    const int l = lane_id();
+    if (do_xsum && (l >> 4) == 0) {                      // every row of the ones-product holds the column sums: take row 0
+#pragma unroll
+        for (int n = 0; n < WM; ++n) {
+            const int m = m_blk + wm0 + n * 16 + l;
+            if (m < a.M) {
+                if (a.xsum_zstride > 0) a.xsum[(long)bz * a.xsum_zstride + m] = xsacc[n][0];
+                else atomicAdd(a.xsum + m, xsacc[n][0]);
+            }
+        }
+    }
+    f32x4 bias4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint4 noext = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        const int m = m_blk + wm0 + mt * 16 + (l & 15);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+            if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], noext, acc[nt][mt], m, n0, 1.0f, bz);
+        }
+    }
+}
+
+// =====================================================================================================
 // W-stationary streaming kernel for TALL-SKINNY products: M = tokens (10^4 .. 10^6), K * sizeof(T) <= 512 bytes.
 // These are HBM-bound (C <= 224 stages of the U-Net: 45 .. 180 FLOP/B against a ridge of ~310), and the tiled
 // kernel above spends its time in fill / barrier / drain of one or two K steps at 2 waves per SIMD.  Here
@@ -659,6 +781,19 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
     static const long stream_min_m = getenv("FW_GEMM_STREAM_MIN_M") ? atol(getenv("FW_GEMM_STREAM_MIN_M")) : 32768;
     if (!x_trans && splitk == 1 && !accumulate && x_op == 0 && w_op == 0 && !xsum && K * sz <= 512 && M >= stream_min_m) {
         return dtype == FW_DT_BF16 ? dispatch_stream<bf16raw>(a, w_trans, st) : dispatch_stream<float>(a, w_trans, st);
+    }
+    // bf16 weight gradients with whole 64-token steps: token-major tiles straight into LDS + transposing LDS reads
+    static const int tn_tr = getenv("FW_GEMM_TN_TR") ? atoi(getenv("FW_GEMM_TN_TR")) : 1;
+    if (tn_tr && dtype == FW_DT_BF16 && x_trans && w_trans && x_op == 0 && w_op == 0 && N > 64 && K % 64 == 0 && a.kper % 64 == 0 &&
+        !bias && act == 0 && !rowscale && !residual && !C2 && a.out_f32 && alpha == 1.0f) {
+        const size_t lds = 4 * 64 * 256;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(fw_cdiv(M, 128), fw_cdiv(N, 128), splitk), dim3(256), lds, st, a);
+        FW_LAUNCH_RET();
     }
     // 128x64 tiles when N is narrow or when 128x128 tiles would leave most of the 256 CUs (2 blocks each) idle
     const bool small_n = N <= 64 || (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk < 384;

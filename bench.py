@@ -143,7 +143,9 @@ def gemm_profile(engine, batch, reps=8):
                 by += M * N * kw[key].element_size()
         stream = (not kw.get('x_trans') and sk == 1 and not kw.get('accumulate') and not kw.get('x_op') and not kw.get('w_op')
                   and kw.get('xsum') is None and K * sz <= 512 and M >= 32768)          # fw_gemm's dispatch rule
-        variant = ('bf16' if x.dtype == torch.bfloat16 else 'f32', 'stream' if stream else (64 if N <= 64 else 128),
+        tr = (x.dtype == torch.bfloat16 and kw.get('w_trans') and not kw.get('x_op') and not kw.get('w_op') and N > 64 and K % 64 == 0
+              and (kw.get('x_trans') or (kw.get('xsum') is None and -(-M // 128) * -(-N // 128) * sk >= 384)))   # gemm_tr_kernel's rule
+        variant = ('bf16' if x.dtype == torch.bfloat16 else 'f32', 'stream' if stream else ('tr' if tr else (64 if N <= 64 else 128)),
                    bool(kw.get('x_trans')), bool(kw.get('w_trans')))
         out.append((variant, (M, N, K, sk), cnt, 2.0 * M * N * K, float(by), dt))
         del g, t, kw, x, w
@@ -310,7 +312,8 @@ def main():
         # the variant's launches are priced one by one against max(FLOPs / MFMA peak, bytes / HBM peak); `bound` is the
         # side that sets most of that time, `achieved` / `peak` are quoted in its unit, `frac` = roofline time / measured
         hbm = by / PEAK_HBM > fl / peak
-        kname = f'gemm_stream_kernel<{v[0]},wT={int(v[3])}>' if v[1] == 'stream' else f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>'
+        kname = (f'gemm_stream_kernel<{v[0]},wT={int(v[3])}>' if v[1] == 'stream' else f'gemm_tr_kernel<xT={int(v[2])}>' if v[1] == 'tr'
+                 else f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>')
         res['roofline'] = {'bound': 'hbm' if hbm else 'mfma', 'kernel': kname,
                            'achieved': round((by / tt / 1e9) if hbm else (fl / tt / 1e12), 2),
                            'peak': (PEAK_HBM / 1e9) if hbm else (peak / 1e12), 'unit': 'GB/s' if hbm else 'TFLOP/s',

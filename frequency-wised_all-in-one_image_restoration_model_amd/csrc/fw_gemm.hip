@@ -428,9 +428,13 @@ FW_DEV uint4 frag_tr256(const char* tile, int m0, int chunk) {
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs a) {
+// XT = true : X token-major as well (dW = dY^T x; bias gradient by ones-MFMA).
+// XT = false: X k-contiguous [M][K] (dX = dY W with W stored [K][N]): its tile is the 128-byte-row image of gemm_kernel
+//             (global_load_lds + frag_sw), only W takes the transposing path.
+template <bool XT>
+__global__ __launch_bounds__(256) void gemm_tr_kernel(GemmArgs a) {
     using T = bf16raw;
-    constexpr int KT = 64, WM = 4, TILE = 64 * 256;      // tokens per step, m tiles per wave, bytes per operand tile
+    constexpr int KT = 64, WM = 4, TILE = 64 * 256;      // k per step, m tiles per wave, bytes per operand tile (= 128 * LDS_ROW)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     auto xs = [&](int i) -> char* { return smem + i * 2 * TILE; };
     auto ws = [&](int i) -> char* { return smem + i * 2 * TILE + TILE; };
@@ -456,27 +460,26 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs a) {
     zero_acc(acc);
 #pragma unroll
     for (int m = 0; m < WM; ++m) xsacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_xsum = a.xsum != nullptr && by == 0 && wn0 == 0;          // wave-uniform
+    const bool do_xsum = XT && a.xsum != nullptr && by == 0 && wn0 == 0;    // wave-uniform
     const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // bf16 1.0 x 8
 
-    if (nsteps > 0) {
-        glds_issue_km(a.X, a.ldx, m_blk, a.M, k_begin, xs(0));
-        glds_issue_km(a.W, a.ldw, n_blk, a.N, k_begin, ws(0));
-    }
+    auto issue = [&](int k0, int buf) {
+        if constexpr (XT) glds_issue_km(a.X, a.ldx, m_blk, a.M, k0, xs(buf));
+        else glds_issue<T, BM>(a.X, a.ldx, m_blk, a.M, k0 * 2, xs(buf));
+        glds_issue_km(a.W, a.ldw, n_blk, a.N, k0, ws(buf));
+    };
+    if (nsteps > 0) issue(k_begin, 0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
-        if (s + 1 < nsteps) {
-            glds_issue_km(a.X, a.ldx, m_blk, a.M, k_begin + (s + 1) * KT, xs(cur ^ 1));
-            glds_issue_km(a.W, a.ldw, n_blk, a.N, k_begin + (s + 1) * KT, ws(cur ^ 1));
-        }
+        if (s + 1 < nsteps) issue(k_begin + (s + 1) * KT, cur ^ 1);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             uint4 af[4], bfr[WM];
 #pragma unroll
             for (int m = 0; m < 4; ++m) af[m] = frag_tr256(ws(cur), wn0 + 16 * m, c);
 #pragma unroll
-            for (int n = 0; n < WM; ++n) bfr[n] = frag_tr256(xs(cur), wm0 + 16 * n, c);
+            for (int n = 0; n < WM; ++n) bfr[n] = XT ? frag_tr256(xs(cur), wm0 + 16 * n, c) : frag_sw(xs(cur), wm0 + 16 * n, c);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -501,17 +504,39 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmArgs a) {
     }
     f32x4 bias4[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bias4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const uint4 noext = make_uint4(0, 0, 0, 0);
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+        bias4[nt] = epi_bias(a, n0 < a.N ? n0 : 0, bz);
+    }
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt) {
         const int m = m_blk + wm0 + mt * 16 + (l & 15);
+        const int mc = m < a.M ? m : a.M - 1;
+        const float rs = a.rowscale ? a.rowscale[mc / a.rows_per_scale] : 1.0f;
+        uint4 ext[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
-            if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], noext, acc[nt][mt], m, n0, 1.0f, bz);
+            epi_fetch<T>(a, ext[nt], mc, n0 < a.N ? n0 : 0, bz);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+            if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], ext[nt], acc[nt][mt], m, n0, rs, bz);
         }
     }
+}
+
+template <bool XT>
+int launch_tr(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = 4 * 64 * 256;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tr_kernel<XT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_tr_kernel<XT>, dim3(fw_cdiv(a.M, 128), fw_cdiv(a.N, 128), a.splitk), dim3(256), lds, st, a);
+    FW_LAUNCH_RET();
 }
 
 // =====================================================================================================
@@ -782,18 +807,13 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
     if (!x_trans && splitk == 1 && !accumulate && x_op == 0 && w_op == 0 && !xsum && K * sz <= 512 && M >= stream_min_m) {
         return dtype == FW_DT_BF16 ? dispatch_stream<bf16raw>(a, w_trans, st) : dispatch_stream<float>(a, w_trans, st);
     }
-    // bf16 weight gradients with whole 64-token steps: token-major tiles straight into LDS + transposing LDS reads
-    static const int tn_tr = getenv("FW_GEMM_TN_TR") ? atoi(getenv("FW_GEMM_TN_TR")) : 1;
-    if (tn_tr && dtype == FW_DT_BF16 && x_trans && w_trans && x_op == 0 && w_op == 0 && N > 64 && K % 64 == 0 && a.kper % 64 == 0 &&
-        !bias && act == 0 && !rowscale && !residual && !C2 && a.out_f32 && alpha == 1.0f) {
-        const size_t lds = 4 * 64 * 256;
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(fw_cdiv(M, 128), fw_cdiv(N, 128), splitk), dim3(256), lds, st, a);
-        FW_LAUNCH_RET();
+    // bf16 products whose W is stored [K][N] (weight gradients: X token-major too; input gradients: X k-contiguous), whole
+    // 64-deep K steps: W (and X) tiles go to LDS as they are and are read with transposing LDS reads (gemm_tr_kernel)
+    static const int use_tr = getenv("FW_GEMM_TR") ? atoi(getenv("FW_GEMM_TR")) : 3;
+    if (dtype == FW_DT_BF16 && w_trans && x_op == 0 && w_op == 0 && N > 64 && K % 64 == 0 && a.kper % 64 == 0 && ldw % 8 == 0) {
+        if (x_trans && (use_tr & 1) && ldx % 8 == 0) return launch_tr<true>(a, st);
+        static const long tr_min_tiles = getenv("FW_GEMM_TR_MIN_TILES") ? atol(getenv("FW_GEMM_TR_MIN_TILES")) : 384;
+        if (!x_trans && (use_tr & 2) && !xsum && (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk >= tr_min_tiles) return launch_tr<false>(a, st);
     }
     // 128x64 tiles when N is narrow or when 128x128 tiles would leave most of the 256 CUs (2 blocks each) idle
     const bool small_n = N <= 64 || (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk < 384;

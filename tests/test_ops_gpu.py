@@ -103,12 +103,24 @@ def test_gemm_c28_padded_rows(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('M,N,K', [(300, 56, 168), (1024, 448, 256), (512, 224, 56)])
+@pytest.mark.parametrize('M,N,K', [(300, 56, 168), (1024, 448, 256), (512, 224, 56), (12300, 508, 192)])
 def test_gemm_nn_dx(dtype, M, N, K):
-    """dX[M,N] = dY[M,K] @ W[K,N]  (W stored [K][N] -> w_trans)"""
+    """dX[M,N] = dY[M,K] @ W[K,N]  (W stored [K][N] -> w_trans).  The last shape (>= 384 tiles, K % 64 == 0) takes the bf16
+    kernel that reads W with transposing LDS reads (gemm_tr_kernel<false>), including its GELU' epilogue and bf16 output."""
     dy, w = q(rnd(M, K), dtype), q(rnd(K, N, seed=1) * 0.1, dtype)
-    y = ops().gemm(dy.to(DEV, dtype), w.to(DEV, dtype), M, N, K, w_trans=True, out_dtype=torch.float32)
+    ldn = (N + 7) // 8 * 8
+    wp = torch.full((K, ldn), float('nan')); wp[:, :N] = w
+    wd = wp.to(DEV, dtype)[:, :N]
+    y = ops().gemm(dy.to(DEV, dtype), wd, M, N, K, w_trans=True, out_dtype=torch.float32)
     close(y, dy @ w, TOL[dtype], 'NN')
+    aux = q(rnd(M, N, seed=5), dtype)
+    out = torch.full((M, ldn), 5.0, device=DEV, dtype=dtype)
+    ops().gemm(dy.to(DEV, dtype), wd, M, N, K, w_trans=True, out=out[:, :N], act=2, aux=aux.to(DEV, dtype))
+    a64 = aux.double()
+    gp = 0.5 * (1 + torch.erf(a64 / math.sqrt(2))) + a64 * torch.exp(-0.5 * a64 * a64) / math.sqrt(2 * math.pi)
+    close(out[:, :N], (dy.double() @ w.double()) * gp, TOL[dtype], 'NN gelu-grad epilogue')
+    if ldn > N:
+        assert float((out[:, N:].float() - 5.0).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

@@ -26,6 +26,9 @@ def per_kernel(d, counter):
 
 
 def short(name):
+    m = re.search(r'gemm_tr_kernel<(true|false)>', name)
+    if m:
+        return f'gemm_tr_kernel<xT={int(m.group(1) == "true")}>'
     m = re.search(r'gemm_(stream_)?kernel<([^>]*)>', name)
     if not m:
         return None

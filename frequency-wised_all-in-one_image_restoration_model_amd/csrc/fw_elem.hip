@@ -436,22 +436,38 @@ __global__ __launch_bounds__(256) void inproj_bwd_kernel(const float* __restrict
     for (long i = gtid(); i < nstripes * C; i += gstride()) {
         const int c = (int)(i % C); const long st = i / C;
         float g[27], gb = 0.f;
+#pragma unroll
         for (int t = 0; t < 27; ++t) g[t] = 0.f;
         for (long tok = st * STRIPE; tok < ntok && tok < (st + 1) * STRIPE; ++tok) {
             const int x = (int)(tok % W); const int y = (int)((tok / W) % H); const long b = tok / ((long)W * H);
-            float d = dy[tok * ldy + c];
-            if (out[tok * ldo + c] <= 0.f) d *= slope;
-            gb += d;
+            // branch-free: the 27 image taps are read from clamped coordinates (independent loads, issued together) and
+            // zeroed by a 0/1 factor -- a load under a lane-varying branch is waited for before the next one is issued
+            float px[27];
+#pragma unroll
             for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    const int yy = y + ky - 1;
-                    if (yy < 0 || yy >= H) continue;
+                    int yy = y + ky - 1; yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+#pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int xx = x + kx - 1;
-                        if (xx < 0 || xx >= W) continue;
-                        g[ci * 9 + ky * 3 + kx] += d * img[((b * 3 + ci) * H + yy) * W + xx];
+                        int xx = x + kx - 1; xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                        px[ci * 9 + ky * 3 + kx] = img[((b * 3 + ci) * H + yy) * W + xx];
                     }
                 }
+            float d = dy[tok * ldy + c];
+            const float o = out[tok * ldo + c];
+            d = o <= 0.f ? d * slope : d;
+            gb += d;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float dyk = (y + ky - 1 >= 0 && y + ky - 1 < H) ? d : 0.f;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float dk = (x + kx - 1 >= 0 && x + kx - 1 < W) ? dyk : 0.f;
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) g[ci * 9 + ky * 3 + kx] += dk * px[ci * 9 + ky * 3 + kx];
+                }
+            }
         }
         atomicAdd(&red[c * 28 + 27], gb);
         for (int t = 0; t < 27; ++t) atomicAdd(&red[c * 28 + t], g[t]);
@@ -537,21 +553,30 @@ __global__ __launch_bounds__(256) void outproj_bwd_w_kernel(const float* __restr
     for (long i = gtid(); i < nstripes * C; i += gstride()) {
         const int c = (int)(i % C); const long st = i / C;
         float g[27], gb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
         for (int t = 0; t < 27; ++t) g[t] = 0.f;
         for (long tok = st * STRIPE; tok < ntok && tok < (st + 1) * STRIPE; ++tok) {
             const int x = (int)(tok % W); const int y = (int)((tok / W) % H); const long b = tok / ((long)W * H);
-            float d[3];
-            for (int co = 0; co < 3; ++co) { d[co] = dout[((b * 3 + co) * H + y) * W + x]; gb[co] += d[co]; }
+            float d[3], f[9];                              // branch-free: 9 clamped feature taps issued together, zeroed by a 0/1 factor
+#pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const int yy = y + ky - 1;
-                if (yy < 0 || yy >= H) continue;
+                int yy = y + ky - 1; yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+#pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int xx = x + kx - 1;
-                    if (xx < 0 || xx >= W) continue;
-                    const float f = fea[((b * H + yy) * W + xx) * ldf + c];
-                    for (int co = 0; co < 3; ++co) g[co * 9 + ky * 3 + kx] += d[co] * f;
+                    int xx = x + kx - 1; xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                    f[ky * 3 + kx] = fea[((b * H + yy) * W + xx) * ldf + c];
                 }
             }
+#pragma unroll
+            for (int co = 0; co < 3; ++co) { d[co] = dout[((b * 3 + co) * H + y) * W + x]; gb[co] += d[co]; }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float fv = (y + ky - 1 >= 0 && y + ky - 1 < H && x + kx - 1 >= 0 && x + kx - 1 < W) ? f[ky * 3 + kx] : 0.f;
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) g[co * 9 + ky * 3 + kx] += d[co] * fv;
+                }
         }
         if (c == 0) for (int co = 0; co < 3; ++co) atomicAdd(&red[C * 27 + co], gb[co]);
         for (int t = 0; t < 27; ++t) atomicAdd(&red[c * 27 + t], g[t]);

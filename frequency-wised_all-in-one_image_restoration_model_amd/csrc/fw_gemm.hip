@@ -549,7 +549,7 @@ int launch_tr(const GemmArgs& a, hipStream_t st) {
 //     all columns of the panel, and the strip after next is requested before the epilogue of the current one.
 // 2 workgroups = 16 independent waves per CU keep loads, MFMAs and stores of different strips in flight together.
 template <typename T, int NCH, bool WT, bool EXT>
-__global__ __launch_bounds__(512, 2) void gemm_stream_kernel(GemmArgs a, int bnp) {   // 2nd argument: waves per SIMD (2 workgroups per CU = 4)
+__global__ __launch_bounds__(512, (NCH == 2 && !EXT) ? 4 : 2) void gemm_stream_kernel(GemmArgs a, int bnp) {   // 2nd argument: waves per SIMD (2 workgroups per CU = 4)
     constexpr int SZ = TT<T>::SZ, E = TT<T>::E16;
     constexpr int RL = NCH * 64;                          // bytes of K per LDS row (NCH even: whole 128-byte swizzle groups)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -609,6 +609,10 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(GemmArgs a, int bnp
             }
         }
     }
+    {                                                     // bias of the panel's columns (zeros when there is none / past N)
+        float* sb = reinterpret_cast<float*>(smem + (size_t)bnp * RL);
+        for (int i = threadIdx.x; i < bnp; i += 512) sb[i] = (a.bias && n_blk + i < a.N) ? a.bias[n_blk + i] : 0.f;
+    }
     __syncthreads();                                      // the only barrier: from here on the waves run independently
 
     const int strips = (a.M + 31) >> 5;
@@ -641,6 +645,10 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(GemmArgs a, int bnp
             }
         }
     };
+    // vmcnt counts loads AND stores in issue order: a global load issued after stores cannot be waited for without waiting for
+    // those stores to be acknowledged (1-2 us).  The bias therefore comes from LDS (staged with the panel): without a row-dependent
+    // operand (EXT) the epilogue issues no global load at all and its stores never block the wave.
+    const float* sbias = reinterpret_cast<const float*>(smem + (size_t)bnp * RL);
     int strip = blockIdx.x * 8 + wave;
     if (strip < strips) issue_x(strip);
     for (; strip < strips; strip += stride) {
@@ -688,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(GemmArgs a, int bnp
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int n0 = n_blk + nb * 64 + i * 16 + ((l >> 4) << 2);
-                    if (m < a.M && n0 < a.N) epi_apply<T>(a, epi_bias(a, n0, 0), ext[i], acc[i][mt], m, n0, rs[mt], 0);
+                    if (m < a.M && n0 < a.N) epi_apply<T>(a, *reinterpret_cast<const f32x4*>(sbias + (n0 - n_blk)), ext[i], acc[i][mt], m, n0, rs[mt], 0);
                 }
             }
         }
@@ -701,10 +709,10 @@ int launch_stream(const GemmArgs& a, hipStream_t st) {
     const int maxb = ((64 * 1024) / RL) & ~63;                      // panel columns that fit 64 KB (2 workgroups per CU)
     const int ny = fw_cdiv(a.N, maxb);
     const int bnp = fw_cdiv(fw_cdiv(a.N, ny), 64) * 64;
-    const size_t lds = (size_t)bnp * RL;
+    const size_t lds = (size_t)bnp * RL + (size_t)bnp * 4;       // W panel + bias of its columns
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<T, NCH, WT, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<T, NCH, WT, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize, 66 * 1024);
         attr_done = true;
     }
     const int strips = fw_cdiv(a.M, 32);

@@ -32,6 +32,7 @@
 // ready-made fragments from L2.  The backward pass needs B1 twice (for P' in dV and for
 // dP = a dP' + c B1(dP')) and gets d(lambda) from three inner products.
 #include "fw_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -719,7 +720,8 @@ extern "C" int fw_attn_bwd(int dtype, int D, int nkt, int lfs, const void* q, co
     a.nwin = B * (H / 8) * (W / 8);
     a.dout = (const char*)dout; a.lddo = lddo; a.dq = (char*)dq; a.dk = (char*)dk; a.dv = (char*)dv;
     a.dk2 = (char*)dk2; a.dv2 = (char*)dv2; a.ldd = ldd; a.dbias = dbias; a.dcoef = dcoef;
-    int chunks = 1024 / (heads * L);          // 4-wave workgroups, 2 per CU: about two rounds of the chip
+    static const int bwd_wgs = getenv("FW_ATTN_BWD_WGS") ? atoi(getenv("FW_ATTN_BWD_WGS")) : 1024;
+    int chunks = bwd_wgs / (heads * L);          // 4-wave workgroups, 2 per CU: about two rounds of the chip
     if (chunks < 1) chunks = 1;
     if (chunks > a.nwin) chunks = a.nwin;
     a.chunks = chunks;

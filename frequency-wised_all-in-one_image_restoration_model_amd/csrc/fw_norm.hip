@@ -6,6 +6,7 @@
 //   bwd : dx[f32] = (dres?) + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * gamma
 //         dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy      (block partials -> atomicAdd)
 #include "fw_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -174,7 +175,10 @@ int ln_fwd_launch(const float* x, long ldx, const float* g, const float* b, void
     FW_LAUNCH_RET();
 }
 static inline int ln_group(int C) { return C <= 64 ? 16 : (C <= 128 ? 32 : 64); }
-static inline int ln_bwd_grid(int rows, int C) { return min(fw_cdiv(rows, 256 / ln_group(C)), 2048); }
+static inline int ln_bwd_grid(int rows, int C) {
+    static const int cap = getenv("FW_LN_BWD_GRID") ? atoi(getenv("FW_LN_BWD_GRID")) : 1024;
+    return min(fw_cdiv(rows, 256 / ln_group(C)), cap);
+}
 
 template <typename T, int G>
 int ln_bwd_launch(const void* dy, long lddy, const float* x, long ldx, const float* g, const float* mean,

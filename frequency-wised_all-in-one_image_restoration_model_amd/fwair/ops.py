@@ -32,11 +32,15 @@ def gemm(x, w, M, N, K, *, x_trans=False, w_trans=False, x_op=0, w_op=0, out=Non
     return out
 
 
+import os as _os
+_SPLITK_BLOCKS = int(_os.environ.get('FW_SPLITK_BLOCKS', '512'))       # tuning knob of pick_splitk (blocks in flight aimed at)
+
+
 def pick_splitk(M, N, K, dtype):
     """Split factor of a weight-gradient GEMM (small M x N output, long reduction K = tokens).  Rule fitted to a sweep on
     MI355X (tools/splitk_sweep.py): about 512 blocks in flight, at least 512 reduction rows (8 K-steps) per block."""
     tiles = ((M + 127) // 128) * ((N + 63) // 64 if N <= 64 else (N + 127) // 128)
-    sk = max(1, min(512 // max(tiles, 1), K // 512))
+    sk = max(1, min(_SPLITK_BLOCKS // max(tiles, 1), K // 512))
     if sk > 1 and (tiles * sk) % 8:                          # fw_gemm deals contiguous eighths of the tile order to the 8 XCDs
         for cand in (sk + 1, sk - 1, sk + 2, sk + 3):
             if cand > 1 and (tiles * cand) % 8 == 0 and K // cand >= 256:

@@ -56,7 +56,7 @@ def pick_splitk(M, N, K, dtype):
 # whose results nobody reads before the optimizer step.  Inside a backward pass they are queued and folded by ONE
 # fw_slab_reduce_multi launch when the pass ends (autograd engine callback) instead of one tiny launch each.
 _pending = []            # (slab, nz, n, zstride, dst, dst2, off2, n2)
-_flush_registered = [False]
+_flush_registered = [None]      # graph-task id of the backward pass whose end-of-pass callback is queued
 _keepalive = []          # pinned host tables referenced by captured HIP graphs (their memcpy nodes re-read them on replay)
 
 
@@ -99,14 +99,17 @@ def slab_reduce(slab, nz, n, zstride, dst, dst2=None, off2=0, n2=0, defer=False)
     if not defer or not _in_backward():
         call('fw_slab_reduce', slab, nz, n, zstride, dst, 1, dst2, off2, n2 if dst2 is not None else 0)
         return
-    _pending.append((slab, nz, n, zstride, dst, dst2, off2, n2 if dst2 is not None else 0))
-    if not _flush_registered[0]:
-        _flush_registered[0] = True
+    task = torch._C._current_graph_task_id()
+    if _flush_registered[0] != task:                       # a new backward pass (an earlier one may have died before its callback ran)
+        if _flush_registered[0] is not None and _pending:
+            _pending.clear()                               # partials of a pass that never finished: their gradients are void anyway
+        _flush_registered[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(flush_slabs)
+    _pending.append((slab, nz, n, zstride, dst, dst2, off2, n2 if dst2 is not None else 0))
 
 
 def flush_slabs():
-    _flush_registered[0] = False
+    _flush_registered[0] = None
     if not _pending:
         return
     items = list(_pending)

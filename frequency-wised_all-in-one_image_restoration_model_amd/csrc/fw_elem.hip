@@ -623,9 +623,9 @@ __global__ void ce0_loss_kernel(const float* __restrict__ logits, float* __restr
 // ------------------------------------------------------------------------------------------------
 // optimizer: Adam (torch.optim.Adam defaults, train.py:63) + low-precision shadow; MoCo EMA
 // ------------------------------------------------------------------------------------------------
-// hyper (device, f32[4]): lr, beta1^t, beta2^t, -- ; advanced by adam_tick_kernel so that a captured
+// hyper (device, f32[4]): lr, beta1^t, beta2^t, t ; advanced by adam_tick_kernel so that a captured
 // HIP graph replays the right bias correction and learning rate every step.
-__global__ void adam_tick_kernel(float* __restrict__ hyper, float b1, float b2) { hyper[1] *= b1; hyper[2] *= b2; }
+__global__ void adam_tick_kernel(float* __restrict__ hyper, float b1, float b2) { hyper[1] *= b1; hyper[2] *= b2; hyper[3] += 1.f; }
 template <typename T>
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             T* __restrict__ shadow, long n, const float* __restrict__ hyper, float b1, float b2, float eps) {

@@ -46,6 +46,24 @@ class TrainLossFn(torch.autograd.Function):
         return dres, None, dlog, None, None
 
 
+class ContrastLossFn(torch.autograd.Function):
+    """mean_i CE(logits_i, 0) alone (phase 1 of train.py:82-86: the encoder is trained on the contrastive loss only)."""
+
+    @staticmethod
+    def forward(ctx, logits, gscale):
+        logits = logits.contiguous()
+        out = torch.zeros(1, dtype=torch.float32, device=logits.device)
+        dlog = torch.empty_like(logits)
+        L, B, N = logits.shape
+        call('fw_ce0_loss', logits, dlog, L * B, N, float(gscale), out)
+        ctx.save_for_backward(dlog)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ctx.saved_tensors[0], None
+
+
 def train_loss(restored, clean, logits, w, gscale=1.0):
     """-> (total [scalar tensor], l1, contrast); total is differentiable (its backward seeds the kernels' gradients)."""
     v = TrainLossFn.apply(restored, clean, logits, w, gscale)
@@ -118,11 +136,16 @@ class GradAllReducer:
         if wire_dtype != torch.float32:
             self._wire = torch.empty(min(n, bucket_elems), dtype=wire_dtype, device=flat_g.device)
 
-    def __call__(self):
+    def __call__(self, upto=None):
+        """upto: only the first `upto` elements carry gradients (phase 1: the query-encoder slice)."""
         if self.world == 1:
             return
         works = []
         for s, e in self.buckets:
+            if upto is not None:
+                if s >= upto:
+                    break
+                e = min(e, upto)
             g = self.flat_g[s:e]
             if self._wire is None:
                 works.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, g))
@@ -162,7 +185,10 @@ class TrainEngine:
         attach_flat_grads(self.trainable, self.flat_g)
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
-        self.hyper = torch.tensor([lr, 1.0, 1.0, 0.0], dtype=torch.float32, device=dev)
+        # Adam step counts: torch.optim.Adam (train.py:63) creates a parameter's state at its FIRST gradient, so after the
+        # encoder-only epochs the decoder's bias correction starts from step 1 -- two hyper vectors {lr, beta1^t, beta2^t, t}
+        self.hyper = torch.tensor([lr, 1.0, 1.0, 0.0], dtype=torch.float32, device=dev)          # query encoder segment [0, n_enc)
+        self.hyper_rest = torch.tensor([lr, 1.0, 1.0, 0.0], dtype=torch.float32, device=dev)     # everything else [n_enc, n)
         # bf16 operand shadows of every 2-D weight whose rows stay 16-byte aligned: written by the Adam / EMA kernels
         self.shadow_p = self.shadow_k = None
         if Fn.config.compute_dtype == torch.bfloat16:
@@ -213,6 +239,22 @@ class TrainEngine:
 
     def set_lr(self, lr):
         self.hyper[0:1].fill_(float(lr))
+        self.hyper_rest[0:1].fill_(float(lr))
+
+    def optimizer_state(self):
+        """Everything a resume needs beside the model's state_dict (flat moments + step counters, host tensors)."""
+        return {'m': self.m.cpu(), 'v': self.v.cpu(), 'hyper': self.hyper.cpu(), 'hyper_rest': self.hyper_rest.cpu()}
+
+    def load_optimizer_state(self, st):
+        self.m.copy_(st['m']); self.v.copy_(st['v'])
+        self.hyper.copy_(st['hyper']); self.hyper_rest.copy_(st['hyper_rest'])
+
+    def resync(self):
+        """After load_state_dict(): the parameters changed under the engine -- refresh the bf16 operand shadows."""
+        if self.shadow_p is not None:
+            call('fw_cast_flat', 1, self.flat_p, self.shadow_p, self.n)
+            call('fw_cast_flat', 1, self.flat_k, self.shadow_k, self.n_enc)
+        Fn.config.shadow_epoch += 1
 
     def _ema(self):
         call('fw_ema', 1 if self.shadow_k is not None else 0, self.flat_k, self.flat_p, self.shadow_k, self.n_enc, self.net.E.E.m)
@@ -225,11 +267,64 @@ class TrainEngine:
         total.backward()
         return torch.stack([total.detach(), l1, contrast])
 
-    def _optim(self):
+    def _optim(self, phase=2):
+        sh = 1 if self.shadow_p is not None else 0
+        ne = self.n_enc
         call('fw_adam_tick', self.hyper, self.betas[0], self.betas[1])
-        call('fw_adam', 1 if self.shadow_p is not None else 0, self.flat_p, self.flat_g, self.m, self.v, self.shadow_p, self.n, self.hyper,
-             self.betas[0], self.betas[1], self.eps)
+        call('fw_adam', sh, self.flat_p, self.flat_g, self.m, self.v, self.shadow_p, ne, self.hyper, self.betas[0], self.betas[1], self.eps)
+        if phase == 2 and self.n > ne:
+            call('fw_adam_tick', self.hyper_rest, self.betas[0], self.betas[1])
+            call('fw_adam', sh, self.flat_p[ne:], self.flat_g[ne:], self.m[ne:], self.v[ne:],
+                 self.shadow_p[ne:] if self.shadow_p is not None else None, self.n - ne, self.hyper_rest, self.betas[0], self.betas[1], self.eps)
         Fn.config.shadow_epoch += 1
+
+    # ---- phase 1 (train.py:82-86): encoder only, contrastive loss only -------------------------------------------------
+    def _fwd_bwd_p1(self, xq, xk):
+        self.flat_g[:self.n_enc].zero_()
+        _, logits, _, _ = self.net.E(x_query=xq, x_key=xk)
+        loss = ContrastLossFn.apply(torch.stack(logits, 0), 1.0 / self.allreduce.world)
+        loss.backward()
+        return loss.detach()
+
+    def step_phase1(self, xq, xk):
+        """One encoder-only step.  Captured into its own HIP graphs on first use (same replay scheme as `step`)."""
+        if not self.use_graph:
+            out = self._fwd_bwd_p1(xq, xk)
+            self.allreduce(self.n_enc)
+            self._optim(1)
+            return out
+        if getattr(self, '_p1', None) is None:
+            static = (xq.clone(), xk.clone())
+            snap = self._snapshot()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self._fwd_bwd_p1(*static); self.allreduce(self.n_enc); self._optim(1)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            single = self.allreduce.world == 1
+            ops.reserve_capture_tables()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                out = self._fwd_bwd_p1(*static)
+                if single:
+                    self._optim(1)
+            g2 = None
+            if not single:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    self._optim(1)
+            self._restore(snap)
+            self._p1 = (static, g1, g2, out)
+        static, g1, g2, out = self._p1
+        if xq is not static[0]:
+            static[0].copy_(xq, non_blocking=True); static[1].copy_(xk, non_blocking=True)
+        g1.replay()
+        if g2 is not None:
+            self.allreduce(self.n_enc)
+            g2.replay()
+        return out
 
     def step_eager(self, xq, xk, clean):
         out = self._fwd_bwd(xq, xk, clean)
@@ -238,9 +333,23 @@ class TrainEngine:
         self.last = out
         return out
 
+    def _snapshot(self):
+        """Model + optimizer state before the warm-up steps a capture needs (they are real steps: lazily built tables, shadow
+        caches and the DropPath plan must exist before a graph can be recorded) -- restored afterwards, so that the first replay
+        is the first training step."""
+        return ({k: v.clone() for k, v in self.net.state_dict().items()}, self.m.clone(), self.v.clone(), self.hyper.clone(),
+                self.hyper_rest.clone())
+
+    def _restore(self, snap):
+        sd, m, v, h, hr = snap
+        self.net.load_state_dict(sd)                        # in-place copies: the flat views stay where they are
+        self.m.copy_(m); self.v.copy_(v); self.hyper.copy_(h); self.hyper_rest.copy_(hr)
+        self.resync()
+
     def capture(self, xq, xk, clean, warmup=2):
         """Warm up eagerly on a side stream, then capture forward+backward (and, single-GPU, the optimizer) into HIP graphs."""
         self._static = (xq.clone(), xk.clone(), clean.clone())
+        snap = self._snapshot()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -260,6 +369,7 @@ class TrainEngine:
             self._g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g2, pool=self._g1.pool()):
                 self._optim()
+        self._restore(snap)
         self._graph = True
 
     def step(self, xq, xk, clean):

@@ -705,42 +705,53 @@ def set_droppath_override(fn):
 
 
 class _DropPathPool:
-    """All DropPath row scales of one training step from ONE draw.  The calls of a step come in a fixed order; the first step
-    records (samples, keep) of every call while drawing one by one, later steps draw a single vector at droppath_begin()
-    and hand out slices -- 3 tiny kernels per step instead of 5 per block."""
+    """All DropPath row scales of one training step from ONE draw.  The calls of a step come in a fixed order; the first complete
+    step records (samples, keep) of every call while drawing one by one, later steps draw a single vector at begin() and hand
+    out slices -- 3 tiny kernels per step instead of 5 per block.  Any deviation from the recorded plan (another model, batch
+    or phase) falls back to per-call draws for the rest of that step and records afresh from the next one."""
 
     def __init__(self):
-        self.plan, self.keep_vec, self.cursor, self.offset, self.pool, self.recording = [], None, 0, 0, None, True
+        self.plan, self.keep_vec, self.cursor, self.offset, self.pool = [], None, 0, 0, None
+        self.state = 'record'                                # 'record' -> 'ready' (plan finalised) ; 'dirty' = give up for this step
 
     def begin(self, device):
-        if self.recording and self.plan and self.cursor == len(self.plan):
+        if self.state == 'record' and self.plan and not torch.cuda.is_current_stream_capturing():
+            # the previous step recorded a full plan: finalise it (host -> device copy: never while a graph is being captured)
             self.keep_vec = torch.cat([torch.full((n,), k, dtype=torch.float32) for n, k in self.plan]).to(device)
-            self.recording = False
+            self.state = 'ready'
+        elif self.state == 'dirty' or (self.state == 'ready' and self.cursor != len(self.plan)):
+            self.plan, self.state = [], 'record'             # the last step did not follow the plan: record this one
+        elif self.state == 'record':
+            self.plan = []
         self.cursor = self.offset = 0
-        if not self.recording:
+        if self.state == 'ready':
             self.pool = torch.floor(self.keep_vec + torch.rand(self.keep_vec.numel(), device=device)) / self.keep_vec
-        elif self.plan:
-            self.plan = []                                   # an incomplete first pass (e.g. an eval forward in between): record again
 
     def draw(self, nsamples, keep, device):
-        if not self.recording:
+        if self.state == 'ready':
             i = self.cursor
             if i < len(self.plan) and self.plan[i] == (nsamples, keep):
                 out = self.pool[self.offset:self.offset + nsamples]
                 self.cursor, self.offset = i + 1, self.offset + nsamples
                 return out
-            self.__init__()                                  # the model or batch changed: fall back and record anew
-        self.plan.append((nsamples, keep))
-        self.cursor = len(self.plan)
+            self.state = 'dirty'
+        elif self.state == 'record':
+            self.plan.append((nsamples, keep))
         return torch.floor(keep + torch.rand(nsamples, device=device)) / keep
 
 
-_dp_pool = _DropPathPool()
+_dp_pools = {}
+_dp_current = [None]
 
 
-def droppath_begin(device):
-    """Call once at the start of every training forward (net.model.AirNet.forward does)."""
-    _dp_pool.begin(device)
+def droppath_begin(device, key='step'):
+    """Call once at the start of every training forward (net.model does).  key: one plan per kind of step (full model /
+    encoder only), so alternating phases do not invalidate each other's plan."""
+    pool = _dp_pools.get(key)
+    if pool is None:
+        pool = _dp_pools[key] = _DropPathPool()
+    _dp_current[0] = pool
+    pool.begin(device)
 
 
 def droppath_scale(name, nsamples, rate, training, device):
@@ -748,4 +759,6 @@ def droppath_scale(name, nsamples, rate, training, device):
         return None
     if _dp_override is not None:
         return _dp_override(name, nsamples, rate, device)
-    return _dp_pool.draw(nsamples, 1.0 - rate, device)
+    if _dp_current[0] is None:
+        droppath_begin(device)
+    return _dp_current[0].draw(nsamples, 1.0 - rate, device)

@@ -50,8 +50,10 @@ class Encoder(nn.Module):
         encoder = globals()[opt.encoder_type + 'Encoder']
         self.E = MoCo(opt=opt, base_encoder=encoder, dim=opt.encoder_dim, K=opt.batch_size * 3)     # net/model.py:35
 
-    def forward(self, x_query, x_key):
+    def forward(self, x_query, x_key, _step_begun=False):
         if self.training:
+            if not _step_begun:                              # called on its own (phase 1 of train.py:82-86): a training step of its own
+                _Fn.droppath_begin(x_query.device, 'encoder')
             fea, logits, labels, inter = self.E(x_query, x_key)
             return fea, logits, labels, inter
         fea, inter = self.E(x_query, x_query)
@@ -69,8 +71,8 @@ class AirNet(nn.Module):
     def forward(self, x_query, x_key):
         _apply_dtype(self.opt)
         if self.training:
-            _Fn.droppath_begin(x_query.device)
-            fea, logits, labels, inter = self.E(x_query, x_key)
+            _Fn.droppath_begin(x_query.device, 'airnet')
+            fea, logits, labels, inter = self.E(x_query, x_key, True)
             restored = self.R(x_query, inter)
             return restored, logits, labels
         fea, inter = self.E(x_query, x_query)

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Throughput training driver beside the reference's train.py.
+
+Same schedule as train.py: `--epochs_encoder` epochs of encoder-only contrastive training (train.py:82-86), then the
+full loss l1 + w * contrast (:87-92); the learning-rate rule of :142-149; the log lines of :98-117 (train.log,
+options.log); the final checkpoint `ckpt/epoch_<E>.pth` = net.state_dict() (:120-129).  Beyond the reference: one
+process per GPU under torchrun (batch-sharded replicas, RCCL gradient all-reduce), the fused HIP-graph engine,
+per-epoch checkpoints and resume (`--save_every`, `--resume`; optimizer moments travel in `epoch_<E>.opt.pth`).
+
+    python train_ddp.py --de_type denoising_15 denoising_25 denoising_50 --degradation_embedding_method all_3_bands \\
+        --contrast_loss_weight 0.6 --compute_dtype bf16 [--per_gpu_batch 16] [--synthetic_steps 100]
+    python -m torch.distributed.run --nproc-per-node 8 train_ddp.py ...
+
+Data: the reference's `utils.dataset_utils.TrainDataset` when that package is importable (put the reference root on
+PYTHONPATH behind this directory) -- each rank draws its own shard; `--synthetic_steps N` trains on N synthetic batches
+per epoch instead (no dataset on disk needed).
+"""
+import argparse
+import os
+import sys
+import time
+
+_own = argparse.ArgumentParser(add_help=False)
+_own.add_argument('--per_gpu_batch', type=int, default=0, help='samples per GPU and step (default: len(de_type), the reference batch)')
+_own.add_argument('--synthetic_steps', type=int, default=0, help='train on this many synthetic batches per epoch')
+_own.add_argument('--resume', type=str, default='', help='checkpoint epoch_<E>.pth to continue from (its .opt.pth beside it)')
+_own.add_argument('--save_every', type=int, default=0, help='also checkpoint every this many epochs')
+_own.add_argument('--no_graph', action='store_true', help='eager launches instead of HIP-graph replay')
+_ARGS, _rest = _own.parse_known_args()
+sys.argv = [sys.argv[0]] + _rest                       # option.py parses sys.argv at import (reference option.py:3)
+
+import torch                                            # noqa: E402
+
+from fwair import engine as E                           # noqa: E402
+from fwair.synthetic import synth_batch                 # noqa: E402
+from net.model import AirNet                            # noqa: E402
+from option import options as opt                       # noqa: E402
+
+
+def lr_for_next_epoch(epoch):
+    """train.py:142-149, applied at the end of `epoch`."""
+    if epoch <= opt.epochs_encoder:
+        return opt.lr * (0.1 ** (epoch // 60))
+    return 0.0001 * (0.5 ** ((epoch - opt.epochs_encoder) // 125))
+
+
+def sigma_of(task):
+    return int(task.split('_')[1]) if task.startswith('denoising_') and task.split('_')[1].isdigit() else 25
+
+
+def batches(epoch, rank, world, B, dev):
+    if _ARGS.synthetic_steps > 0:
+        sig = [sigma_of(t) for t in opt.de_type] or [25]
+        for i in range(_ARGS.synthetic_steps):
+            clean, d1, d2 = synth_batch(B, opt.patch_size, sig[i % len(sig)], 1234 + rank + 1000 * (epoch * _ARGS.synthetic_steps + i), dev)
+            yield d1, d2, clean
+        return
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from utils.dataset_utils import TrainDataset        # the reference's dataset (needs its root on PYTHONPATH and the data on disk)
+    ds = TrainDataset(opt)
+    sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, drop_last=True)
+    sampler.set_epoch(epoch)
+    for (_, d1, d2, c1, _) in DataLoader(ds, batch_size=B, sampler=sampler, pin_memory=True, drop_last=True, num_workers=opt.num_workers):
+        yield d1.to(dev, non_blocking=True), d2.to(dev, non_blocking=True), c1.to(dev, non_blocking=True)
+
+
+def main():
+    rank, local, world = E.init_distributed()
+    dev = torch.device('cuda', local if world > 1 else opt.cuda)
+    torch.cuda.set_device(dev)
+    B = _ARGS.per_gpu_batch or opt.batch_size
+    opt.batch_size = B                                   # MoCo queue K = 3 * per-replica batch (net/model.py:35)
+    w = opt.contrast_loss_weight if opt.contrast_loss_weight is not None else opt.default_contrast_loss_weight
+    if rank == 0:
+        os.makedirs(opt.output_path, exist_ok=True)
+        os.makedirs(opt.ckpt_path, exist_ok=True)
+        with open(opt.output_path + 'options.log', 'w') as f:           # train.py:39-46
+            f.write(f"|{'=' * 151}|\n")
+            for key, value in opt.__dict__.items():
+                f.write(f"|{str(key):>50s}|{str(value):<100s}|\n")
+            f.write(f"|{'=' * 151}|\n")
+    net = AirNet(opt).to(dev).train()
+    eng = E.TrainEngine(net, lr=opt.lr, contrast_loss_weight=w, use_graph=not _ARGS.no_graph,
+                        grad_wire_dtype=torch.bfloat16 if opt.grad_allreduce_dtype == 'bf16' else torch.float32)
+    start = 0
+    if _ARGS.resume:
+        net.load_state_dict(torch.load(_ARGS.resume, map_location=dev, weights_only=True))
+        st = torch.load(_ARGS.resume[:-4] + '.opt.pth', map_location='cpu', weights_only=True)
+        eng.load_optimizer_state(st)
+        eng.resync()
+        start = int(st['epoch']) + 1
+        eng.set_lr(lr_for_next_epoch(start - 1))
+    log = open(opt.output_path + 'train.log', 'a' if _ARGS.resume else 'w') if rank == 0 else None
+
+    def save(epoch):
+        if rank != 0:
+            return
+        torch.save(net.state_dict(), opt.ckpt_path + 'epoch_' + str(epoch + 1) + '.pth')                  # train.py:126
+        st = eng.optimizer_state()
+        st['epoch'] = torch.tensor(epoch)
+        torch.save(st, opt.ckpt_path + 'epoch_' + str(epoch + 1) + '.opt.pth')
+
+    for epoch in range(start, opt.epochs):
+        t0, n, out = time.time(), 0, None
+        for d1, d2, clean in batches(epoch, rank, world, B, dev):
+            out = eng.step_phase1(d1, d2) if epoch < opt.epochs_encoder else eng.step(d1, d2, clean)
+            n += 1
+        if out is not None and rank == 0:
+            v = [float(x) for x in out.flatten()]
+            if epoch < opt.epochs_encoder:                                # train.py:98-106
+                line = 'Epoch (%d)  Loss: contrast_loss:%0.4f\n' % (epoch, v[0])
+            else:                                                         # train.py:107-117
+                line = 'Epoch (%d)  Loss: l1_loss:%0.4f contrast_loss:%0.4f\n' % (epoch, v[1], v[2])
+            dt = time.time() - t0
+            print(line.rstrip('\n') + f'   [{n * B * world / max(dt, 1e-9):.1f} images/s]', flush=True)
+            log.write(line)
+            log.flush()
+        if epoch + 1 == opt.epochs or (_ARGS.save_every and (epoch + 1) % _ARGS.save_every == 0):
+            save(epoch)
+        eng.set_lr(lr_for_next_epoch(epoch))
+    if log:
+        log.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

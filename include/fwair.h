@@ -121,7 +121,7 @@ int fw_l1_loss(const float* a, const float* b, float* da, long n, float gscale, 
 int fw_ce0_loss(const float* logits, float* dlogits, int R, int N, float gscale, float* loss, void* stream);
 
 /* ---- Adam (train.py:63,96; torch.optim.Adam defaults) and MoCo EMA (net/utils/moco.py:44-50) ----------
- * hyper: device f32[4] = {lr, beta1^t, beta2^t, 0}; fw_adam_tick advances t so graphs replay correctly. */
+ * hyper: device f32[4] = {lr, beta1^t, beta2^t, t}; fw_adam_tick advances t so graphs replay correctly. */
 int fw_adam_tick(float* hyper, float b1, float b2, void* stream);
 int fw_adam(int shadow_dtype, float* p, const float* g, float* m, float* v, void* shadow, long n, const float* hyper, float b1,
             float b2, float eps, void* stream);

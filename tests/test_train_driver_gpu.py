@@ -1,0 +1,42 @@
+"""The two-phase throughput driver (train_ddp.py) end to end on synthetic data: schedule of train.py
+(encoder-only epochs, then the full loss), its log lines, its final checkpoint format, plus per-epoch checkpoints and resume."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'frequency-wised_all-in-one_image_restoration_model_amd')
+
+
+def run(out, *extra):
+    cmd = [sys.executable, os.path.join(PKG, 'train_ddp.py'), '--de_type', 'denoising_25', '--degradation_embedding_method', 'all_3_bands',
+           '--contrast_loss_weight', '0.6', '--compute_dtype', 'bf16', '--per_gpu_batch', '2', '--synthetic_steps', '2',
+           '--output_path', out, '--epochs_encoder', '1', *extra]
+    r = subprocess.run(cmd, cwd=PKG, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_two_phase_training_and_resume(tmp_path):
+    out = str(tmp_path) + '/'
+    run(out, '--epochs', '3', '--save_every', '2')
+    log = open(out + 'train.log').read().splitlines()
+    assert re.fullmatch(r'Epoch \(0\)  Loss: contrast_loss:\d+\.\d{4}', log[0])                       # train.py:98-106
+    assert re.fullmatch(r'Epoch \(1\)  Loss: l1_loss:\d+\.\d{4} contrast_loss:\d+\.\d{4}', log[1])    # train.py:107-117
+    assert len(log) == 3
+    assert os.path.exists(out + 'options.log')
+    for e in (2, 3):
+        assert os.path.exists(out + f'ckpt/epoch_{e}.pth') and os.path.exists(out + f'ckpt/epoch_{e}.opt.pth')
+    sd = torch.load(out + 'ckpt/epoch_3.pth', map_location='cpu', weights_only=True)
+    assert len(sd) == 2496 and all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+    st = torch.load(out + 'ckpt/epoch_2.opt.pth', map_location='cpu', weights_only=True)
+    assert float(st['hyper'][3]) == 4.0 and float(st['hyper_rest'][3]) == 2.0      # Adam steps: encoder 2 epochs x 2, the rest 1 x 2
+    # resume from epoch 2 and train epoch index 2 again: same number of log lines afterwards (appended), finite losses
+    run(out, '--epochs', '3', '--resume', out + 'ckpt/epoch_2.pth')
+    log2 = open(out + 'train.log').read().splitlines()
+    assert len(log2) == 4 and log2[3].startswith('Epoch (2)  Loss: l1_loss:')

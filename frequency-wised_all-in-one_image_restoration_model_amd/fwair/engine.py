@@ -46,6 +46,23 @@ class TrainLossFn(torch.autograd.Function):
         return dres, None, dlog, None, None
 
 
+class L1LossFn(torch.autograd.Function):
+    """mean |restored - clean| alone (train.py:89), gradient pre-scaled by gscale."""
+
+    @staticmethod
+    def forward(ctx, restored, clean, gscale):
+        restored, clean = restored.contiguous(), clean.contiguous()
+        out = torch.zeros(1, dtype=torch.float32, device=restored.device)
+        dres = torch.empty_like(restored)
+        call('fw_l1_loss', restored, clean, dres, restored.numel(), float(gscale), out)
+        ctx.save_for_backward(dres)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ctx.saved_tensors[0], None, None
+
+
 class ContrastLossFn(torch.autograd.Function):
     """mean_i CE(logits_i, 0) alone (phase 1 of train.py:82-86: the encoder is trained on the contrastive loss only)."""
 
@@ -136,6 +153,29 @@ class GradAllReducer:
         if wire_dtype != torch.float32:
             self._wire = torch.empty(min(n, bucket_elems), dtype=wire_dtype, device=flat_g.device)
 
+    def launch(self, lo, hi):
+        """Asynchronous SUM all-reduce of flat_g[lo:hi] in buckets; returns the work handles (wait with `finish`)."""
+        works = []
+        if self.world == 1 or hi <= lo:
+            return works
+        step = self.buckets[0][1] - self.buckets[0][0]
+        for s in range(lo, hi, step):
+            g = self.flat_g[s:min(hi, s + step)]
+            if self._wire is None:
+                works.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, g))
+            else:                                             # low-precision wire: one staging buffer per bucket in flight
+                w = torch.empty(g.numel(), dtype=self.wire_dtype, device=g.device)
+                w.copy_(g)
+                works.append((dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True), w, g))
+        return works
+
+    @staticmethod
+    def finish(works):
+        for wk, w, g in works:
+            wk.wait()
+            if w is not None:
+                g.copy_(w)
+
     def __call__(self, upto=None):
         """upto: only the first `upto` elements carry gradients (phase 1: the query-encoder slice)."""
         if self.world == 1:
@@ -163,8 +203,10 @@ class GradAllReducer:
 # ---------------------------------------------------------------------------------------------------------------
 class TrainEngine:
     def __init__(self, net, lr=2e-4, contrast_loss_weight=0.6, betas=(0.9, 0.999), eps=1e-8, use_graph=True,
-                 grad_wire_dtype=torch.float32):
+                 grad_wire_dtype=torch.float32, split_backward=False):
         self.net = net
+        self.split_backward = split_backward               # force the two-stage backward on a single GPU too (tests)
+        self._split = self._gsplit = None
         self.w = float(contrast_loss_weight)
         self.betas, self.eps = betas, eps
         self.use_graph = use_graph
@@ -267,6 +309,62 @@ class TrainEngine:
         total.backward()
         return torch.stack([total.detach(), l1, contrast])
 
+    # ---- backward in two stages (data parallel): the decoder's gradients are complete when the decoder's backward is, long before
+    # the encoder's -- their all-reduce runs on RCCL's stream while the encoder backward is still computing
+    def _split_a(self, xq, xk, clean):
+        """zero grads, forward, L1 loss, backward of the DECODER (incl. the lambda heads) down to the encoder's output stack."""
+        self.flat_g.zero_()
+        Fn.droppath_begin(xq.device, 'airnet')
+        _, logits, _, inter = self.net.E(xq, xk, True)
+        stack = inter[0]._fw_stack
+        # cut the tape at the encoder's output: the decoder sees a detached leaf, so `backward` runs ALL of its nodes (a gradient
+        # restricted to `inputs=[stack]` would prune every node that only feeds parameters) and leaves d(stack) in the leaf's .grad
+        cut = stack.detach().requires_grad_(True)
+        inter_d = tuple(cut.unbind(0))
+        inter_d[0]._fw_stack = cut
+        restored = self.net.R(xq, inter_d)
+        gs = 1.0 / self.allreduce.world
+        l1 = L1LossFn.apply(restored, clean, gs)
+        l1.backward()                                        # ends with the fold of the decoder's split partials (ops.flush_slabs)
+        self._split = (stack, cut.grad, torch.stack(logits, 0), l1.detach())
+
+    def _split_b(self):
+        """contrastive loss, backward of the query encoder (heads + body) with the decoder's gradient of the stack added in."""
+        stack, dstack, logits, l1 = self._split
+        c = ContrastLossFn.apply(logits, self.w / self.allreduce.world)
+        torch.autograd.backward([stack, c], [dstack, torch.ones_like(c)])
+        self._split = None
+        cd = c.detach()
+        return torch.cat([l1 + self.w * cd, l1, cd])
+
+    def step_split_eager(self, xq, xk, clean):
+        self._split_a(xq, xk, clean)
+        wa = self.allreduce.launch(self.n_enc, self.n)
+        out = self._split_b()
+        wb = self.allreduce.launch(0, self.n_enc)
+        GradAllReducer.finish(wa); GradAllReducer.finish(wb)
+        self._optim()
+        self.last = out
+        return out
+
+    def _capture_split(self, warmup=2):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.step_split_eager(*self._static)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        ops.reserve_capture_tables()
+        ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self._split_a(*self._static)
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            self._out = self._split_b()
+        with torch.cuda.graph(gc, pool=ga.pool()):
+            self._optim()
+        self._gsplit = (ga, gb, gc)
+
     def _optim(self, phase=2):
         sh = 1 if self.shadow_p is not None else 0
         ne = self.n_enc
@@ -358,6 +456,18 @@ class TrainEngine:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         single = self.allreduce.world == 1
+        self._gsplit = None
+        if self.split_backward or not single:
+            try:
+                self._capture_split(warmup)
+                self._restore(snap)
+                self._graph = True
+                return
+            except Exception as e:                           # never lose the run to the overlap: fall back to reduce-after-backward
+                import warnings
+                warnings.warn(f'fwair: two-stage backward capture failed ({type(e).__name__}: {e}); all-reduce will follow the backward pass')
+                self._gsplit, self._split = None, None
+                torch.cuda.synchronize()
         ops.reserve_capture_tables()
         self._g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g1):
@@ -380,6 +490,16 @@ class TrainEngine:
         sq, sk, sc = self._static
         if xq is not sq:
             sq.copy_(xq, non_blocking=True); sk.copy_(xk, non_blocking=True); sc.copy_(clean, non_blocking=True)
+        if self._gsplit is not None:
+            ga, gb, gc = self._gsplit
+            ga.replay()
+            wa = self.allreduce.launch(self.n_enc, self.n)    # decoder gradients travel while the encoder backward runs
+            gb.replay()
+            wb = self.allreduce.launch(0, self.n_enc)
+            GradAllReducer.finish(wa); GradAllReducer.finish(wb)
+            gc.replay()
+            self.last = self._out
+            return self._out
         self._g1.replay()
         if self._g2 is not None:
             self.allreduce()

@@ -125,3 +125,27 @@ def test_moco_three_steps_fp32():
         ksd = net.E.E.encoder_k.state_dict()
         for n in probe:
             close(ksd[n], g[f'k{step}.' + n], 1e-4, f'EMA {n} step {step}')
+
+
+def test_engine_two_stage_backward_matches_single_pass():
+    """Data-parallel replay scheme (decoder backward | all-reduce of its gradients overlapping the encoder backward | optimizer)
+    forced on one GPU: same losses and same parameters as the single-graph step after 2 steps, fp32, DropPath off."""
+    from fwair import engine as E
+    from fwair import functional as Fn
+    res = []
+    for split in (False, True):
+        net, opt = build('all3')
+        net.train()
+        eng = E.TrainEngine(net, lr=2e-4, contrast_loss_weight=0.6, use_graph=True, split_backward=split)
+        clean, q, k = synth_batch(2, 128, 'split.')
+        outs = [eng.step(q.to(DEV), k.to(DEV), clean.to(DEV)).clone() for _ in range(2)]
+        torch.cuda.synchronize()
+        assert (eng._gsplit is not None) == split
+        res.append((torch.stack(outs).cpu(), eng.flat_p.clone().cpu(), eng.flat_g.clone().cpu()))
+        Fn.config.direct_grads = False
+    (la, pa, ga), (lb, pb, gb) = res
+    close(lb, la, 1e-5, 'losses (total, l1, contrast) over 2 steps')
+    close(gb, ga, 2e-4, 'flat gradient of the second step')
+    # Adam normalises every gradient to about +-lr, so where a gradient is numerically zero the order of the float atomics decides
+    # its sign: compare the bulk, not the maximum
+    assert float((pb - pa).abs().median()) < 1e-7 and float(((pb - pa).abs() > 1e-5).float().mean()) < 0.02, 'parameters after 2 Adam steps'

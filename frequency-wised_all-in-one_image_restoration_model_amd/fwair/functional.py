@@ -715,7 +715,7 @@ class _DropPathPool:
         self.state = 'record'                                # 'record' -> 'ready' (plan finalised) ; 'dirty' = give up for this step
 
     def begin(self, device):
-        if self.state == 'record' and self.plan and not torch.cuda.is_current_stream_capturing():
+        if self.state == 'record' and self.plan and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
             # the previous step recorded a full plan: finalise it (host -> device copy: never while a graph is being captured)
             self.keep_vec = torch.cat([torch.full((n,), k, dtype=torch.float32) for n, k in self.plan]).to(device)
             self.state = 'ready'

@@ -81,3 +81,26 @@ def test_band_masks_equal_oracle():
     for kind, size, n in (('frequency_decompose_1', 0.5, 128), ('frequency_decompose_1', 1.0, 64), ('frequency_decompose', 1 / 3., 64)):
         for a, b in zip(lfs.band_masks_shifted(kind, size, n, n), O.band_masks(kind, size, n, n)):
             assert torch.equal(a, b)
+
+
+def test_droppath_plan_and_tile_grid():
+    """Host logic without a GPU: the one-draw-per-step DropPath plan (record -> ready -> dirty on deviation -> record) and the
+    tile grid of the device-side evaluation (test.py:47-48)."""
+    import torch
+    from fwair import functional as Fn
+    from fwair.evaluate import tile_origins
+    assert tile_origins(200, 128) == [0, 72] and tile_origins(128, 128) == [0] and tile_origins(264, 128) == [0, 128, 136]
+    p = Fn._DropPathPool()
+    states = []
+    for _ in range(3):
+        p.begin('cpu')
+        a, b = p.draw(4, 0.9, 'cpu'), p.draw(6, 0.8, 'cpu')
+        assert a.shape == (4,) and b.shape == (6,)
+        assert set((a * 0.9).round().tolist()) <= {0.0, 1.0} and set((b * 0.8).round().tolist()) <= {0.0, 1.0}
+        states.append(p.state)
+    assert states == ['record', 'ready', 'ready'] and p.plan == [(4, 0.9), (6, 0.8)]
+    p.begin('cpu')
+    p.draw(4, 0.9, 'cpu')
+    assert p.draw(5, 0.8, 'cpu').shape == (5,) and p.state == 'dirty'          # another batch size: per-call draws for this step
+    p.begin('cpu')
+    assert p.state == 'record' and p.plan == []

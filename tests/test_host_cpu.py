@@ -104,3 +104,31 @@ def test_droppath_plan_and_tile_grid():
     assert p.draw(5, 0.8, 'cpu').shape == (5,) and p.state == 'dirty'          # another batch size: per-call draws for this step
     p.begin('cpu')
     assert p.state == 'record' and p.plan == []
+
+
+def test_device_input_pipeline_semantics():
+    """fwair/augment.py against the reference's numpy semantics (image_utils.py:133-160 on HWC arrays, dataset_utils.py:126)."""
+    import numpy as np
+    import torch
+    from fwair import augment as A
+    rs = np.random.RandomState(0)
+    hwc = rs.randint(0, 256, (24, 40, 3)).astype(np.uint8)
+
+    def ref(img, mode):
+        k, flip = mode // 2, mode % 2 == 1
+        out = np.rot90(img, k=k) if k else img
+        return np.flipud(out) if flip else out
+
+    chw = torch.from_numpy(hwc).permute(2, 0, 1)
+    for mode in range(8):
+        got = A.augment(chw, mode).permute(1, 2, 0).numpy()
+        assert np.array_equal(got, ref(hwc, mode)), f'mode {mode}'
+    g = torch.Generator().manual_seed(5)
+    noisy = A.add_noise(chw, 25, g)
+    assert noisy.dtype == torch.uint8 and noisy.shape == chw.shape
+    d = noisy.float() - chw.float()
+    assert 15 < float(d.std()) < 30                                       # sigma 25 on the uint8 grid, clipped at the ends
+    d1, d2, c1, c2 = A.training_pair(chw, 16, sigma=15, generator=g)
+    assert d1.shape == d2.shape == c1.shape == c2.shape == (3, 16, 16) and float(c1.max()) <= 1.0
+    b = A.training_batch([chw, chw], 16, [15, 50], g)
+    assert len(b) == 4 and b[0].shape == (2, 3, 16, 16)

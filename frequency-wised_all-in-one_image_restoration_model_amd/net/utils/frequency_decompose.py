@@ -16,6 +16,52 @@ from fwair import lfs
 from fwair.lib import call
 
 
+def _bands(x, mask, mode):
+    """x: f32 [n, N, N] -> mode 0: Re IDFT2(mask_b * DFT2 x) [nb, n, N, N];  mode 1: (re, im) of mask_b * DFT2 x [nb, n, N, N, 2];
+    mode 2: |.| in fftshift-ed coordinates."""
+    n, N = x.shape[0], x.shape[1]
+    nb = mask.shape[0]
+    fr = torch.empty((n, N, N), dtype=torch.float32, device=x.device)
+    fi = torch.empty_like(fr)
+    call('fw_dft2_fwd', x, fr, fi, n, N)
+    out = torch.empty((nb, n, N, N, 2) if mode == 1 else (nb, n, N, N), dtype=torch.float32, device=x.device)
+    call('fw_dft2_bands', fr, fi, mask, out, n, N, nb, mode)
+    return out
+
+
+class _BandsFn(torch.autograd.Function):
+    """Differentiable band decomposition (the frequency L1 loss of train.py:69-70,90-91 back-propagates through it).
+    The DFT is linear, so the backward pass is the adjoint transform, evaluated by the same kernels:
+      mode 0 (band images)   out_b = Re(A_b x), A_b = F^-1 M_b F is Hermitian for a real mask  =>  dx = sum_b Re(A_b dout_b)
+      mode 1 (spectra)       out_b = M_b F x (re, im)                                          =>  dx = N^2 Re F^-1( sum_b M_b (dre_b + i dim_b) )"""
+
+    @staticmethod
+    def forward(ctx, x, mask, mode):
+        ctx.mask, ctx.mode = mask, mode
+        return _bands(x, mask, mode)
+
+    @staticmethod
+    def backward(ctx, dout):
+        mask, mode = ctx.mask, ctx.mode
+        dout = dout.contiguous().float()
+        nb, n, N = dout.shape[0], dout.shape[1], dout.shape[2]
+        if mode == 0:
+            dx = None
+            for b in range(nb):
+                t = _bands(dout[b], mask[b:b + 1], 0)[0]
+                dx = t if dx is None else dx + t
+            return dx, None, None
+        if mode == 1:
+            m = mask.unsqueeze(1)                                            # [nb, 1, N, N]
+            gr = (dout[..., 0] * m).sum(0).contiguous()
+            gi = (dout[..., 1] * m).sum(0).contiguous()
+            ones = torch.ones((1, N, N), dtype=torch.float32, device=dout.device)
+            out = torch.empty((1, n, N, N), dtype=torch.float32, device=dout.device)
+            call('fw_dft2_bands', gr, gi, ones, out, n, N, 1, 0)             # Re IDFT2 (already divided by N^2)
+            return out[0] * float(N * N), None, None
+        raise NotImplementedError("FrequencyDecompose(inverse='visual') is a magnitude plot, not a differentiable output")
+
+
 class FrequencyDecompose(nn.Module):
     def __init__(self, type, size, h, w, inverse=True):
         super().__init__()
@@ -35,32 +81,26 @@ class FrequencyDecompose(nn.Module):
         return self._masks[key]
 
     def forward(self, x):
-        if x.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError('FrequencyDecompose backward (only needed by --num_frequency_bands_l1) is not on the hot path yet')
         B, C, N = x.shape[0], x.shape[1], x.shape[2]
-        x = x.detach().contiguous().float()
+        need_grad = x.requires_grad and torch.is_grad_enabled()
         n = B * C
         if self.type not in ['frequency_decompose', 'frequency_decompose_1']:
+            if need_grad:                                                # mean / residual split: two lines of tensor algebra, autograd-native
+                mean = x.float().mean(dim=(-2, -1), keepdim=True).expand_as(x)
+                return torch.stack([mean, x.float() - mean], 0)
+            xc = x.detach().contiguous().float()
             out = torch.empty((2, B, C, N, x.shape[3]), dtype=torch.float32, device=x.device)
-            call('fw_dc_split', x, out, n, N * x.shape[3])
+            call('fw_dc_split', xc, out, n, N * x.shape[3])
             return out
         assert N == self.h and x.shape[3] == self.w
         mask = self._mask(x.device)
         nb = mask.shape[0]
-        fr = torch.empty((n, N, N), dtype=torch.float32, device=x.device)
-        fi = torch.empty_like(fr)
-        call('fw_dft2_fwd', x, fr, fi, n, N)
-        if self.inverse is True:
-            out = torch.empty((nb, B, C, N, N), dtype=torch.float32, device=x.device)
-            call('fw_dft2_bands', fr, fi, mask, out, n, N, nb, 0)
-        elif self.inverse is False:
-            out = torch.empty((nb, B, C, N, N, 2), dtype=torch.float32, device=x.device)
-            call('fw_dft2_bands', fr, fi, mask, out, n, N, nb, 1)
-        elif self.inverse == 'visual':
-            out = torch.empty((nb, B, C, N, N), dtype=torch.float32, device=x.device)
-            call('fw_dft2_bands', fr, fi, mask, out, n, N, nb, 2)
+        mode = 0 if self.inverse is True else 1 if self.inverse is False else 2
+        assert self.inverse in (True, False, 'visual')
+        xf = x.contiguous().float().reshape(n, N, N)
+        out = _BandsFn.apply(xf, mask, mode) if need_grad else _bands(xf.detach(), mask, mode)
+        out = out.reshape((nb, B, C, N, N, 2) if mode == 1 else (nb, B, C, N, N))
+        if mode == 2:
             # the reference's fftshift has no dim argument: it also rolls the batch and channel axes (:32)
             out = torch.roll(out, shifts=(B // 2, C // 2), dims=(1, 2))
-        else:
-            raise AssertionError
         return out

@@ -486,6 +486,25 @@ def test_dft_band_decomposition(N):
     close(o, O.frequency_decompose(x.view(1, 3, N, N), 'frequency_decompose_dc', 0.5, N, N)[:, 0], 2e-5, 'dc split')
 
 
+@pytest.mark.parametrize('inverse', [True, False])
+@pytest.mark.parametrize('kind,size', [('frequency_decompose', 1 / 3.), ('frequency_decompose_1', 0.5), ('frequency_decompose_dc', 0.5)])
+def test_frequency_decompose_backward(kind, size, inverse):
+    """FrequencyDecompose as a differentiable module (the frequency L1 loss of train.py:69-70,90-91): forward and input gradient
+    against the oracle's torch.fft restatement."""
+    from net.utils.frequency_decompose import FrequencyDecompose
+    N = 64
+    x = rnd(2, 3, N, N)
+    xo = x.clone().double().requires_grad_(True)
+    ref = O.frequency_decompose(xo, kind, size, N, N, inverse)
+    wgt = rnd(*ref.shape, seed=9).double()
+    (ref * wgt).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    out = FrequencyDecompose(kind, size, N, N, inverse=inverse)(xd)
+    close(out, ref, 2e-5, 'forward')
+    (out * wgt.to(DEV).float()).sum().backward()
+    close(xd.grad, xo.grad, 5e-5, 'input gradient')
+
+
 # ------------------------------------------------------------------------------------------------ encoder head
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_bn_lrelu_gap(dtype):

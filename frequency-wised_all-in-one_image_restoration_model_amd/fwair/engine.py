@@ -203,8 +203,9 @@ class GradAllReducer:
 # ---------------------------------------------------------------------------------------------------------------
 class TrainEngine:
     def __init__(self, net, lr=2e-4, contrast_loss_weight=0.6, betas=(0.9, 0.999), eps=1e-8, use_graph=True,
-                 grad_wire_dtype=torch.float32, split_backward=False):
+                 grad_wire_dtype=torch.float32, split_backward=False, freq_l1=None):
         self.net = net
+        self.freq_l1 = freq_l1                             # (FrequencyDecompose(inverse=False), weight): the optional frequency L1 term of train.py:69-70,90-91
         self.split_backward = split_backward               # force the two-stage backward on a single GPU too (tests)
         self._split = self._gsplit = None
         self.w = float(contrast_loss_weight)
@@ -302,10 +303,20 @@ class TrainEngine:
         call('fw_ema', 1 if self.shadow_k is not None else 0, self.flat_k, self.flat_p, self.shadow_k, self.n_enc, self.net.E.E.m)
         Fn.config.shadow_epoch += 1
 
+    def _freq_term(self, restored, clean):
+        """weight * L1(decompose(restored), decompose(clean)), pre-scaled like the other loss gradients (differentiable module)."""
+        dec, wgt = self.freq_l1
+        d = (dec(restored.float()) - dec(clean)).abs().mean()
+        return d * wgt
+
     def _fwd_bwd(self, xq, xk, clean):
         self.flat_g.zero_()
         restored, logits, labels = self.net(x_query=xq, x_key=xk)
         total, l1, contrast = train_loss(restored, clean, torch.stack(logits, 0), self.w, 1.0 / self.allreduce.world)
+        if self.freq_l1 is not None:
+            f = self._freq_term(restored, clean)
+            (total + f / self.allreduce.world).backward()
+            return torch.stack([(total + f).detach(), l1 + f.detach(), contrast])
         total.backward()
         return torch.stack([total.detach(), l1, contrast])
 
@@ -325,7 +336,12 @@ class TrainEngine:
         restored = self.net.R(xq, inter_d)
         gs = 1.0 / self.allreduce.world
         l1 = L1LossFn.apply(restored, clean, gs)
-        l1.backward()                                        # ends with the fold of the decoder's split partials (ops.flush_slabs)
+        if self.freq_l1 is not None:
+            f = self._freq_term(restored, clean)
+            (l1 + f * gs).backward()
+            l1 = l1.detach() + f.detach()
+        else:
+            l1.backward()                                    # ends with the fold of the decoder's split partials (ops.flush_slabs)
         self._split = (stack, cut.grad, torch.stack(logits, 0), l1.detach())
 
     def _split_b(self):

@@ -81,7 +81,12 @@ def main():
                 f.write(f"|{str(key):>50s}|{str(value):<100s}|\n")
             f.write(f"|{'=' * 151}|\n")
     net = AirNet(opt).to(dev).train()
-    eng = E.TrainEngine(net, lr=opt.lr, contrast_loss_weight=w, use_graph=not _ARGS.no_graph,
+    freq = None
+    if opt.num_frequency_bands_l1 != -1:                     # train.py:69-70: frequency L1 on the (re, im) spectra of the bands
+        from net.utils.frequency_decompose import FrequencyDecompose
+        freq = (FrequencyDecompose('frequency_decompose', 1. / opt.num_frequency_bands_l1, opt.patch_size, opt.patch_size, inverse=False),
+                opt.frequency_l1_loss_weight)
+    eng = E.TrainEngine(net, lr=opt.lr, contrast_loss_weight=w, use_graph=not _ARGS.no_graph, freq_l1=freq,
                         grad_wire_dtype=torch.bfloat16 if opt.grad_allreduce_dtype == 'bf16' else torch.float32)
     start = 0
     if _ARGS.resume:

@@ -40,3 +40,14 @@ def test_two_phase_training_and_resume(tmp_path):
     run(out, '--epochs', '3', '--resume', out + 'ckpt/epoch_2.pth')
     log2 = open(out + 'train.log').read().splitlines()
     assert len(log2) == 4 and log2[3].startswith('Epoch (2)  Loss: l1_loss:')
+
+
+def test_frequency_l1_term(tmp_path):
+    """--num_frequency_bands_l1 (train.py:69-70,90-91): the extra L1 on band spectra back-propagates through the differentiable
+    FrequencyDecompose and shows up in the logged l1_loss."""
+    out = str(tmp_path) + '/'
+    a = run(out + 'a/', '--epochs', '1', '--epochs_encoder', '0')
+    b = run(out + 'b/', '--epochs', '1', '--epochs_encoder', '0', '--num_frequency_bands_l1', '3')
+    la = float(re.search(r'l1_loss:(\d+\.\d+)', open(out + 'a/train.log').read()).group(1))
+    lb = float(re.search(r'l1_loss:(\d+\.\d+)', open(out + 'b/train.log').read()).group(1))
+    assert lb > la > 0 and lb < 100 * la + 10, (la, lb)

@@ -119,6 +119,11 @@ def flush_slabs():
     host = _host_table(num * 12 + num + 1)
     tab, prefix = host[:num * 12].view(num, 12), host[num * 12:]
     rows, offs, total = [], [0], 0
+    seen = {}
+    for it in items:                                           # destinations written by more than one entry need atomics
+        for t in (it[4], it[5]):
+            if t is not None:
+                seen[t.data_ptr()] = seen.get(t.data_ptr(), 0) + 1
     for slab, nz, n, zstride, dst, dst2, off2, n2 in items:
         end = off2 + n2 if dst2 is not None else n
         nchunks = ((end + 3) // 4 + 63) // 64                  # 64 lanes x 16 bytes
@@ -126,8 +131,10 @@ def flush_slabs():
         splits = (nz + zper - 1) // zper
         upw = max(1, 32 // zper)                               # units per wave: >= ~32 KB moved by every wave
         blocks = (nchunks * splits + 4 * upw - 1) // (4 * upw)
+        shared = seen[dst.data_ptr()] > 1 or (dst2 is not None and seen[dst2.data_ptr()] > 1)
+        unaligned = dst.data_ptr() % 16 or (dst2 is not None and dst2.data_ptr() % 16)
         rows.append((slab.data_ptr(), dst.data_ptr(), dst2.data_ptr() if dst2 is not None else 0, n, zstride, off2, n2, nz, zper,
-                     nchunks, upw, 0))
+                     nchunks, upw, int(splits > 1 or shared or bool(unaligned))))
         total += blocks
         offs.append(total)
     tab.copy_(torch.tensor(rows, dtype=torch.int64))

@@ -39,7 +39,7 @@ int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op, const voi
 int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, float* dst2, long off2, long n2,
                    void* stream);
 /* Many slabs in one launch (ops.flush_slabs: every weight-gradient / LayerNorm partial of a backward pass is folded once,
- * at its end).  tab: device int64 [num][12] = slab, dst, dst2, n, zstride, off2, n2, nz, zper, nchunks, upw, 0; prefix: device
+ * at its end).  tab: device int64 [num][12] = slab, dst, dst2, n, zstride, off2, n2, nz, zper, nchunks, upw, atomics; prefix: device
  * int64 [num + 1] block offsets (entry e owns ceil(nchunks * ceil(nz / zper) / (4 * upw)) blocks of 4 waves; a wave folds upw
  * units of 64 columns x zper slab rows).  Every entry ACCUMULATES into dst / dst2. */
 int fw_slab_reduce_multi(const void* tab, const void* prefix, int num, long total_blocks, void* stream);

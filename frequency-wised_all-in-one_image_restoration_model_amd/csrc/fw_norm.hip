@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, l
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres, long lddres,
                                                      float* __restrict__ dx, long lddx, float* __restrict__ partial,
-                                                     long pstride, int rows, int C) {
+                                                     long pstride, int rows, int C, T* __restrict__ twin, long ldtw,
+                                                     const float* __restrict__ twscale, int tw_rows_per_scale) {
     constexpr int RPB = 256 / G;
     const int gl = threadIdx.x % G, gr = threadIdx.x / G;
     const int nv = C >> 2;
@@ -136,6 +137,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, l
                         for (int e = 0; e < 4; ++e) o[e] += rr[e];
                     }
                     *reinterpret_cast<f32x4*>(dx + row * lddx + c4 * 4) = o;
+                    if (twin) {                                  // the operand copy the preceding Linear's backward needs: T(dx * DropPath scale)
+                        const float sc = twscale ? twscale[row / tw_rows_per_scale] : 1.0f;
+                        T* tp = twin + row * ldtw + c4 * 4;
+                        if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(tp) = f32x4{o[0] * sc, o[1] * sc, o[2] * sc, o[3] * sc};
+                        else *reinterpret_cast<uint2*>(tp) = make_uint2(pack_bf2(o[0] * sc, o[1] * sc), pack_bf2(o[2] * sc, o[3] * sc));
+                    }
                 }
             }
         }
@@ -183,9 +190,9 @@ static inline int ln_bwd_grid(int rows, int C) {
 template <typename T, int G>
 int ln_bwd_launch(const void* dy, long lddy, const float* x, long ldx, const float* g, const float* mean,
                   const float* rstd, const float* dres, long lddres, float* dx, long lddx, float* partial, long pstride,
-                  int rows, int C, hipStream_t st) {
+                  int rows, int C, void* twin, long ldtw, const float* twscale, int twrps, hipStream_t st) {
     hipLaunchKernelGGL((ln_bwd_kernel<T, G>), dim3(ln_bwd_grid(rows, C)), dim3(256), 0, st, (const T*)dy, lddy, x, ldx, g, mean, rstd,
-                       dres, lddres, dx, lddx, partial, pstride, rows, C);
+                       dres, lddres, dx, lddx, partial, pstride, rows, C, (T*)twin, ldtw, twscale, twrps);
     FW_LAUNCH_RET();
 }
 
@@ -211,22 +218,31 @@ extern "C" int fw_layernorm_bwd_blocks(int rows, int C) { return ln_bwd_grid(row
 // are folded into dgamma / dbeta (accumulated) by fw_slab_reduce, launched here on the same stream -- unless both are null.
 extern "C" int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, float* dst2, long off2, long n2,
                               void* stream);
-extern "C" int fw_layernorm_bwd(int dtype, const void* dy, long lddy, const float* x, long ldx, const float* gamma,
-                                const float* mean, const float* rstd, const float* dres, long lddres, float* dx,
-                                long lddx, float* dgamma, float* dbeta, float* partial, int rows, int C, void* stream) {
+extern "C" int fw_layernorm_bwd2(int dtype, const void* dy, long lddy, const float* x, long ldx, const float* gamma,
+                                 const float* mean, const float* rstd, const float* dres, long lddres, float* dx,
+                                 long lddx, float* dgamma, float* dbeta, float* partial, int rows, int C, void* twin, long ldtw,
+                                 const float* twscale, int tw_rows_per_scale, void* stream) {
     FW_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0);
     FW_CHECK_ARG(dy && x && gamma && mean && rstd && dx && partial && ((dgamma && dbeta) || (!dgamma && !dbeta)));
+    FW_CHECK_ARG(!twin || (ldtw % 4 == 0 && (!twscale || tw_rows_per_scale > 0)));
     hipStream_t st = (hipStream_t)stream;
     const long pstride = 2L * C;
 #define LN_B(T)                                                                                                      \
     (C <= 64 ? ln_bwd_launch<T, 16>(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, partial, pstride, rows, \
-                                    C, st)                                                                           \
+                                    C, twin, ldtw, twscale, tw_rows_per_scale, st)                                                                           \
              : C <= 128 ? ln_bwd_launch<T, 32>(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, partial,  \
-                                               pstride, rows, C, st)                                                 \
+                                               pstride, rows, C, twin, ldtw, twscale, tw_rows_per_scale, st)                                                 \
                         : ln_bwd_launch<T, 64>(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, partial,  \
-                                               pstride, rows, C, st))
+                                               pstride, rows, C, twin, ldtw, twscale, tw_rows_per_scale, st))
     const int rc = dtype == FW_DT_BF16 ? LN_B(bf16raw) : LN_B(float);
 #undef LN_B
     if (rc || !dgamma) return rc;                  // dgamma == dbeta == null: the caller folds the partials later (fw_slab_reduce_multi)
     return fw_slab_reduce(partial, ln_bwd_grid(rows, C), C, pstride, dgamma, 1, dbeta, C, C, stream);
+}
+
+extern "C" int fw_layernorm_bwd(int dtype, const void* dy, long lddy, const float* x, long ldx, const float* gamma,
+                                const float* mean, const float* rstd, const float* dres, long lddres, float* dx,
+                                long lddx, float* dgamma, float* dbeta, float* partial, int rows, int C, void* stream) {
+    return fw_layernorm_bwd2(dtype, dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, dgamma, dbeta, partial, rows, C,
+                             nullptr, 0, nullptr, 1, stream);
 }

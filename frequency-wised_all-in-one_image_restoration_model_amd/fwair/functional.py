@@ -180,7 +180,11 @@ class LinearFn(torch.autograd.Function):
         bias = ctx.bias
         M, K = x.shape
         N = weight.shape[0]
-        if dy.dtype == torch.float32 and x.dtype != torch.float32 or rowscale is not None:
+        tw = getattr(dy, '_fw_twin', None)
+        if (tw is not None and tw[0].dtype == x.dtype and tw[0].shape == (M, N) and tw[2] == rows_per_scale
+                and (tw[1] is rowscale or (tw[1] is not None and rowscale is not None and tw[1].data_ptr() == rowscale.data_ptr()))):
+            g = tw[0]                                        # LnResFn.backward already wrote T(dy * rowscale)
+        elif dy.dtype == torch.float32 and x.dtype != torch.float32 or rowscale is not None:
             g = act_empty(M, N, x.dtype, x.device)
             call('fw_cast_rows', dt(x.dtype), dy, dy.stride(0), g, g.stride(0), M, N, rowscale, rows_per_scale)
         else:
@@ -204,6 +208,7 @@ class LnResFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta):
         ctx.set_materialize_grads(False)
+        ctx.rs_hint = getattr(x, '_fw_rs', None)            # x came straight out of a residual Linear: (rowscale, rows_per_scale)
         rows, C = x.shape
         y = act_empty(rows, C, config.compute_dtype, x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -220,12 +225,25 @@ class LnResFn(torch.autograd.Function):
         db, rb = _grad_target(ctx.beta)
         if dy is None:
             return dres, None, None
-        dx = ops.layernorm_bwd(aligned(dy), x, gamma, mean, rstd, dg, db, dres=dres, defer=rg is None and rb is None)
+        dy = aligned(dy)
+        twin = None
+        if ctx.rs_hint is not None:
+            # the gradient returned here is the dy of the Linear that produced x; its backward wants T(dy * DropPath scale) as the
+            # operand of two GEMMs -- written by this kernel as a second output instead of a separate cast pass
+            twin = act_empty(x.shape[0], x.shape[1], dy.dtype, x.device)
+        rs, rps = ctx.rs_hint if ctx.rs_hint is not None else (None, 1)
+        dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db, dres=dres, defer=rg is None and rb is None, twin=twin, twscale=rs,
+                               tw_rows_per_scale=rps)
+        if twin is not None:
+            dx._fw_twin = (twin, rs, rps)
         return dx, rg, rb
 
 
 def linear(x, weight, bias=None, residual=None, rowscale=None, rows_per_scale=1, x_pre=None, gelu_out=False, out_f32=False):
-    return LinearFn.apply(x, weight, bias, residual, rowscale, rows_per_scale, x_pre, gelu_out, out_f32)
+    y = LinearFn.apply(x, weight, bias, residual, rowscale, rows_per_scale, x_pre, gelu_out, out_f32)
+    if residual is not None and y.requires_grad and (x.dtype != torch.float32 or rowscale is not None):
+        y._fw_rs = (rowscale, rows_per_scale)               # lets the LayerNorm that consumes y emit this Linear's backward operand
+    return y
 
 
 class QKVFn(torch.autograd.Function):

@@ -193,13 +193,15 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, defer=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, defer=False, twin=None, twscale=None, tw_rows_per_scale=1):
+    """twin: optional T [rows, C] buffer that also receives dx * twscale[row // tw_rows_per_scale] (see fw_layernorm_bwd2)."""
     rows, C = x.shape
     dx = torch.empty((rows, C), dtype=torch.float32, device=x.device)
     nblk = lib().fw_layernorm_bwd_blocks(rows, C)
     partial = torch.empty((nblk, 2 * C), dtype=torch.float32, device=x.device)
-    call('fw_layernorm_bwd', dt(dy.dtype), dy, _ld(dy), x, _ld(x), gamma, mean, rstd, dres,
-         _ld(dres) if dres is not None else 0, dx, _ld(dx), None, None, partial, rows, C)
+    call('fw_layernorm_bwd2', dt(dy.dtype), dy, _ld(dy), x, _ld(x), gamma, mean, rstd, dres,
+         _ld(dres) if dres is not None else 0, dx, _ld(dx), None, None, partial, rows, C,
+         twin, _ld(twin) if twin is not None else 0, twscale, tw_rows_per_scale)
     slab_reduce(partial, nblk, C, 2 * C, dgamma, dbeta, C, C, defer=defer)
     return dx
 

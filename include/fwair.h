@@ -53,6 +53,12 @@ int fw_layernorm_bwd_blocks(int rows, int C);
 int fw_layernorm_bwd(int dtype, const void* dy, long lddy, const float* x, long ldx, const float* gamma, const float* mean,
                      const float* rstd, const float* dres, long lddres, float* dx, long lddx, float* dgamma, float* dbeta,
                      float* partial, int rows, int C, void* stream);
+/* Same, plus an optional second output twin[rows][ldtw] (type T) = dx * twscale[row / tw_rows_per_scale]: the DropPath-scaled
+ * operand copy that the backward of the Linear feeding this residual stream needs (saves its separate cast kernel). */
+int fw_layernorm_bwd2(int dtype, const void* dy, long lddy, const float* x, long ldx, const float* gamma, const float* mean,
+                      const float* rstd, const float* dres, long lddres, float* dx, long lddx, float* dgamma, float* dbeta,
+                      float* partial, int rows, int C, void* twin, long ldtw, const float* twscale, int tw_rows_per_scale,
+                      void* stream);
 
 /* ---- window attention (decoder_Uformer.py:240-293 with :387-409,634-651,678-686,721-729 folded in;
  *      encoder_Uformer.py:152-183 "origin", :256-310 intra / inter band attention) ---------------------

@@ -22,14 +22,14 @@ template <int N> FW_DEV float block_sum(float v, float* red) {      // N threads
 }
 
 // =====================================================================================================
-// 2-D DFT band decomposition, one image per workgroup, N <= 128
+// 2-D DFT band decomposition, N <= 256 (power of two)
 // =====================================================================================================
 // spectrum (unshifted) F[u][v] = sum_{y,x} img[y][x] exp(-2 pi i (u y + v x) / N)  ->  fr, fi [n][N][N]
 // One workgroup = 16 output rows of one image (grid: image x row slice): 8x the parallelism of one image per workgroup, and
 // no redundant work because each slice contracts over y FIRST:  F[u][v] = sum_x ( sum_y img[y][x] w^{uy} ) w^{xv},  w = e^{-2 pi i/N}.
-constexpr int DFT_SL = 16;
+constexpr int DFT_SL = 16, DFT_MAXN = 256;
 __global__ __launch_bounds__(256) void dft2_fwd_kernel(const float* __restrict__ img, float* __restrict__ fr, float* __restrict__ fi, int N) {
-    __shared__ float hr[DFT_SL * 128], hi[DFT_SL * 128], tc[128], ts[128];
+    __shared__ float hr[DFT_SL * DFT_MAXN], hi[DFT_SL * DFT_MAXN], tc[DFT_MAXN], ts[DFT_MAXN];
     const int rows = N < DFT_SL ? N : DFT_SL;
     const int u0 = blockIdx.y * rows;
     const float* x = img + (size_t)blockIdx.x * N * N;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void dft2_fwd_kernel(const float* __restrict__
 // Same slicing (grid: image x band x 16-row slice of y):  out[y][x] = Re sum_v ( sum_u M F[u][v] w^{-uy} ) w^{-vx} / N^2.
 __global__ __launch_bounds__(256) void dft2_band_inv_kernel(const float* __restrict__ fr, const float* __restrict__ fi, const float* __restrict__ mask,
                                                             float* __restrict__ out, int N, int nimg) {
-    __shared__ float kr[DFT_SL * 128], ki[DFT_SL * 128], tc[128], ts[128];
+    __shared__ float kr[DFT_SL * DFT_MAXN], ki[DFT_SL * DFT_MAXN], tc[DFT_MAXN], ts[DFT_MAXN];
     const int rows = N < DFT_SL ? N : DFT_SL;
     const int n = blockIdx.x, band = blockIdx.y, y0 = blockIdx.z * rows;
     const float* Fr = fr + (size_t)n * N * N; const float* Fi = fi + (size_t)n * N * N;
@@ -279,9 +279,10 @@ __global__ void moco_ptr_kernel(long long* __restrict__ ptr, int B, int K) { *pt
 // =====================================================================================================
 // LFS lambda heads
 // =====================================================================================================
-// xbar[i][b][c] = mean_t xhat[t][c], xhat = LayerNorm-normalised (no affine) rows of inter[i][b] ([64 tokens][C])
+// xbar[i][b][c] = mean_t xhat[t][c], xhat = LayerNorm-normalised (no affine) rows of inter[i][b] ([NT tokens][C]; NT = (S/16)^2: 64 at 128x128)
+constexpr int LFS_MAXT = 1024;
 __global__ __launch_bounds__(256) void lfs_xbar_kernel(const float* __restrict__ inter, float* __restrict__ xbar, float* __restrict__ stats, int NT, int C, float eps) {
-    __shared__ float mu[64], rs[64];
+    __shared__ float mu[LFS_MAXT], rs[LFS_MAXT];
     const size_t blk = (size_t)blockIdx.x;                 // (band, b) flattened
     const float* x = inter + blk * NT * C;
     const int w = threadIdx.x >> 6, l = lane_id();
@@ -425,14 +426,14 @@ __global__ __launch_bounds__(64) void lfs_lambda_bwd_kernel(const float* __restr
 
 // spectrum scratch fr/fi: [nimg][N][N] f32 each.
 extern "C" int fw_dft2_fwd(const float* img, float* fr, float* fi, int nimg, int N, void* stream) {
-    FW_CHECK_ARG(img && fr && fi && nimg > 0 && N >= 8 && N <= 128 && (N & (N - 1)) == 0);
+    FW_CHECK_ARG(img && fr && fi && nimg > 0 && N >= 8 && N <= DFT_MAXN && (N & (N - 1)) == 0);
     hipLaunchKernelGGL(dft2_fwd_kernel, dim3(nimg, N < DFT_SL ? 1 : N / DFT_SL), dim3(256), 0, ST, img, fr, fi, N);
     FW_LAUNCH_RET();
 }
 // mode 0: real band images (inverse=True) out [nb][nimg][N][N];  1: (re,im) pairs out [nb][nimg][N][N][2];  2: |.| fftshift-ed ('visual')
 extern "C" int fw_dft2_bands(const float* fr, const float* fi, const float* mask_unshifted, float* out, int nimg, int N, int nbands,
                              int mode, void* stream) {
-    FW_CHECK_ARG(fr && fi && mask_unshifted && out && nimg > 0 && N >= 8 && N <= 128 && (N & (N - 1)) == 0 && nbands > 0 && mode >= 0 && mode <= 2);
+    FW_CHECK_ARG(fr && fi && mask_unshifted && out && nimg > 0 && N >= 8 && N <= DFT_MAXN && (N & (N - 1)) == 0 && nbands > 0 && mode >= 0 && mode <= 2);
     if (mode == 0) {
         hipLaunchKernelGGL(dft2_band_inv_kernel, dim3(nimg, nbands, N < DFT_SL ? 1 : N / DFT_SL), dim3(256), 0, ST, fr, fi, mask_unshifted, out, N, nimg);
     } else {
@@ -498,7 +499,7 @@ extern "C" int fw_moco_enqueue(float* queue, const float* khat, long long* ptr, 
 
 // inter: f32 [nb1*B][NT][C] (bands 1.. of the encoder output, contiguous).  stats: f32 [nb1*B][NT][2].
 extern "C" int fw_lfs_xbar(const float* inter, float* xbar, float* stats, int nb1, int B, int NT, int C, float eps, void* stream) {
-    FW_CHECK_ARG(inter && xbar && stats && NT <= 64 && NT > 0);
+    FW_CHECK_ARG(inter && xbar && stats && NT <= LFS_MAXT && NT > 0);
     hipLaunchKernelGGL(lfs_xbar_kernel, dim3(nb1 * B), dim3(256), 0, ST, inter, xbar, stats, NT, C, eps);
     FW_LAUNCH_RET();
 }

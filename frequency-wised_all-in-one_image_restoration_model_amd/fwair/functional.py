@@ -510,7 +510,7 @@ class OutputProjFn(torch.autograd.Function):
 # encoder contrastive head
 # ---------------------------------------------------------------------------------------------------------------
 class BnLreluGapFn(torch.autograd.Function):
-    """fea: T [B*64, ED*256] viewed as [B][ED][P] -> BatchNorm2d -> LeakyReLU(0.1) -> mean over P  (encoder_Uformer.py:978-982)."""
+    """fea: T [B*(S/16)^2, ED*256] viewed as [B][ED][P] -> BatchNorm2d -> LeakyReLU(0.1) -> mean over P  (encoder_Uformer.py:978-982)."""
 
     @staticmethod
     def forward(ctx, fea, gamma, beta, rmean, rvar, nbt, B, training):
@@ -618,7 +618,7 @@ _lfs_tables = {}
 
 
 class LfsLambdaFn(torch.autograd.Function):
-    """inter: f32 [nb1*B*64, C] (bands 1.. of the encoder output).  params: per block, per band, the 8 tensors
+    """inter: f32 [nb1*B*NT, C] (bands 1.. of the encoder output).  params: per block, per band, the 8 tensors
     (ln.w, ln.b, lin.w, lin.b, mlp0.w, mlp0.b, mlp2.w, mlp2.b).  Returns the flat (a, b, c) coefficient buffer."""
 
     @staticmethod
@@ -630,8 +630,10 @@ class LfsLambdaFn(torch.autograd.Function):
         nblk = len(heads_list)
         inter = inter.contiguous()
         xbar = torch.empty((nb1 * B, C), dtype=torch.float32, device=dev)
-        stats = torch.empty((nb1 * B, 64, 2), dtype=torch.float32, device=dev)
-        call('fw_lfs_xbar', inter, xbar, stats, nb1, B, 64, C, 1e-5)
+        NT = inter.shape[0] // (nb1 * B)                  # tokens of the encoder representation: (S/16)^2, 64 at 128x128
+        ctx.NT = NT
+        stats = torch.empty((nb1 * B, NT, 2), dtype=torch.float32, device=dev)
+        call('fw_lfs_xbar', inter, xbar, stats, nb1, B, NT, C, 1e-5)
         key = (tuple(p.data_ptr() for p in params), B, nb1, str(dev))
         tabs = _lfs_tables.get(key)
         if tabs is None:                    # host-built once per parameter placement (never inside a graph capture)
@@ -706,7 +708,7 @@ class LfsLambdaFn(torch.autograd.Function):
         dxbar = torch.zeros_like(xbar)
         call('fw_lfs_lambda_bwd', xbar, ptab, gt, heads, coef_off, dcoef.contiguous(), save, dxbar, nblk, B, C, nb1)
         dinter = torch.zeros_like(inter)
-        call('fw_lfs_xbar_bwd', inter, stats, dxbar, dinter, nb1, B, 64, C)
+        call('fw_lfs_xbar_bwd', inter, stats, dxbar, dinter, nb1, B, ctx.NT, C)
         return (dinter, None) + tuple(grads)
 
 

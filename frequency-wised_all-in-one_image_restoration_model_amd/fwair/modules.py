@@ -221,13 +221,26 @@ class DecBasicUformerLayer(nn.Module):
             for i in range(depth)])
 
 
+def _resolve_img_size(opt, img_size):
+    """The reference's seam calls `cls(opt)` and so always builds for img_size=128 (net/model.py:17,31), whatever `--patch_size`
+    says; a 64- or 256-pixel patch then fails inside its window partition.  Here the constructor default follows
+    `opt.patch_size`, so the same seam builds the 256x256 model the reference classes give with img_size=256.
+    The bottleneck (S/16) must hold whole 8x8 windows: S is a multiple of 128."""
+    S = int(img_size if img_size is not None else (getattr(opt, 'patch_size', None) or 128))
+    if S < 128 or S % 128:
+        raise NotImplementedError(f'img_size={S}: the five-stage Uformer with 8x8 windows needs a multiple of 128 '
+                                  '(the reference fails in window_partition otherwise)')
+    return S
+
+
 class UformerDecoder(nn.Module):
     """decoder_Uformer.py:835-1171."""
 
-    def __init__(self, opt, img_size=128, in_chans=3, out_chans=3, depths=(2, 2, 8, 8, 2, 8, 8, 2, 2),
+    def __init__(self, opt, img_size=None, in_chans=3, out_chans=3, depths=(2, 2, 8, 8, 2, 8, 8, 2, 2),
                  num_heads=(1, 2, 4, 8, 16, 16, 8, 4, 2), win_size=8, mlp_ratio=4., drop_path_rate=0.1):
         super().__init__()
         self.opt = opt
+        img_size = _resolve_img_size(opt, img_size)
         if getattr(opt, 'debug_mode', False):
             raise NotImplementedError('debug_mode spectra are not produced by the HIP path')
         for m in opt.degradation_embedding_method:
@@ -286,14 +299,15 @@ class UformerDecoder(nn.Module):
         if nb == 0:
             return [None] * len(blocks)
         if isinstance(inter, (tuple, list)):
-            stack = getattr(inter[0], '_fw_stack', None)                        # the encoder's own [L, B, 64, C] buffer
+            stack = getattr(inter[0], '_fw_stack', None)                        # the encoder's own [L, B, (S/16)^2, C] buffer
             if stack is None:
                 stack = torch.stack([t.float() for t in inter[:nb]], 0)
         else:
             stack = inter
         C = stack.shape[-1]
-        assert stack.shape[-2] == 64 and C == 448, 'LFS heads expect the [B, 64, 448] encoder representation'
-        bands = stack[1:nb].reshape((nb - 1) * B * 64, C)
+        NT = stack.shape[-2]
+        assert C == 448, 'LFS heads expect the [B, (S/16)^2, 448] encoder representation'
+        bands = stack[1:nb].reshape((nb - 1) * B * NT, C)
         params = [p for blk in blocks for p in blk.attn.lambda_params()]
         heads = tuple(blk.num_heads for blk in blocks)
         coef = Fn.LfsLambdaFn.apply(bands, (heads, B, nb - 1), *params)
@@ -472,10 +486,11 @@ class Uformer(nn.Module):
 class UformerEncoder(nn.Module):
     """encoder_Uformer.py:926-986."""
 
-    def __init__(self, opt, img_size=128, in_chans=3, out_chans=3):
+    def __init__(self, opt, img_size=None, in_chans=3, out_chans=3):
         super().__init__()
         from net.utils.frequency_decompose import FrequencyDecompose
         self.opt = opt
+        img_size = _resolve_img_size(opt, img_size)
         E = opt.encoder_embed_dim
         self.img_size = img_size
         if not opt.L == 1:
@@ -498,8 +513,8 @@ class UformerEncoder(nn.Module):
         assert mask is None
         opt, L = self.opt, self.opt.L
         B = x.shape[0]
-        if x.shape[-1] != self.img_size:
-            raise NotImplementedError('the encoder is built for 128x128 inputs (encoder_Uformer.py:927)')
+        if x.shape[-1] != self.img_size or x.shape[-2] != self.img_size:
+            raise NotImplementedError(f'the encoder is built for {self.img_size}x{self.img_size} inputs (encoder_Uformer.py:927)')
         x = x.contiguous().float()
         if L != 1:
             x = self.preprocess_decompose(x).reshape(L * B, *x.shape[1:])      # 'l b c h w -> (l b) c h w'

@@ -69,8 +69,8 @@ class FrequencyDecompose(nn.Module):
         assert size > 0 and size <= 1, 'invalid frequency band width(size=%s)' % (size)
         self._masks = {}
         if self.type in ['frequency_decompose', 'frequency_decompose_1']:
-            if h != w or h & (h - 1) or not 8 <= h <= 128:
-                raise NotImplementedError('HIP band decomposition handles square power-of-two maps, 8 <= N <= 128')
+            if h != w or h & (h - 1) or not 8 <= h <= 256:
+                raise NotImplementedError('HIP band decomposition handles square power-of-two maps, 8 <= N <= 256')
             self.num_bands = math.floor(1. / self.size + 0.1)
 
     def _mask(self, device):

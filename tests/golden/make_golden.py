@@ -6,7 +6,7 @@ Imports the unmodified reference through ``oracle/refshim.py`` (timm stand-in, n
 inputs with DropPath neutralised and stores inputs + outputs as small ``.npz`` files
 (``numpy.load`` with ``allow_pickle=False`` reads them) plus the state-dict schema as JSON.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [unit] [model] [moco] [schema]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [unit] [model] [moco] [model256]
 
 A fixture is data (inputs / expected outputs); no reference source text is stored.
 """
@@ -236,6 +236,45 @@ def gen_model():
         json.dump(schemas, f)
 
 
+def gen_model256():
+    """Resolution-generic row: the reference's own classes built with img_size=256 -- the seam `cls(opt)` always
+    takes the 128 default (net/model.py:17,31), so the two registered names are rebound to 256-pixel constructors for this run.
+    One image, all_3_bands / L=3 / freq: eval output, train-mode restored / logits / loss, gradient norms."""
+    import net.model as RM
+    set_opt(batch_size=1, degradation_embedding_method=['all_3_bands'], L=3, encoder_msa_type='freq')
+    keep = RM.UformerEncoder, RM.UformerDecoder
+    RM.UformerEncoder = lambda o: RE.UformerEncoder(o, img_size=256)
+    RM.UformerDecoder = lambda o: RD.UformerDecoder(o, img_size=256)
+    try:
+        t0 = time.time()
+        net = seed_module(AirNet(opt), '')
+    finally:
+        RM.UformerEncoder, RM.UformerDecoder = keep
+    for pq, pk in zip(net.E.E.encoder_q.parameters(), net.E.E.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    clean, q, k = synth_batch(1, 256, 'model256.')
+    net.eval()
+    with torch.no_grad():
+        restored_eval = net(x_query=q, x_key=q)
+    arrs = {'restored_eval': restored_eval, 'psnr_eval': O.psnr(restored_eval, clean), 'psnr_input': O.psnr(q, clean)}
+    net.train()
+    restored, logits, labels = net(x_query=q, x_key=k)
+    CE = torch.nn.CrossEntropyLoss()
+    contrast = sum(CE(logits[i], labels[i]) for i in range(opt.L)) / opt.L
+    l1 = torch.nn.L1Loss()(restored, clean)
+    loss = l1 + opt.contrast_loss_weight * contrast
+    g = grads_of(net, loss)
+    names = sorted(g.keys())
+    arrs.update({'restored_train': restored, 'logits': torch.stack(logits, 0), 'loss': loss, 'l1': l1, 'contrast': contrast,
+                 'grad_names': np.array(names), 'grad_norms': np.array([g[n].norm().item() for n in names]),
+                 'queue_after': net.E.E.queue, 'queue_ptr_after': net.E.E.queue_ptr})
+    for n in ('R.R.output_proj.proj.0.weight', 'R.R.input_proj.proj.0.weight', 'E.E.encoder_q.uformer.input_proj.proj.0.weight',
+              'R.R.bottleneck_0.blocks.1.attn.relative_position_bias_table'):
+        arrs['g.' + n] = g[n]
+    save('model256_all3', **arrs)
+    print('model256 done in %.1fs' % (time.time() - t0))
+
+
 def gen_moco():
     """Three consecutive train-mode steps of the encoder side only (net.E), SGD lr 0.05 on the
     query encoder in between, so that EMA, queue rotation and pointer wrap are all exercised."""
@@ -277,3 +316,5 @@ if __name__ == '__main__':
             gen_model()
         if 'moco' in what:
             gen_moco()
+        if 'model256' in what:
+            gen_model256()

@@ -65,6 +65,18 @@ def test_unsupported_configurations_fail_loudly():
         AirNet(make_opt('all3', encoder_type='ResNet', decoder_type='ResNet'))
 
 
+def test_patch_size_sets_the_model_resolution():
+    """`opt.patch_size` reaches encoder / decoder `img_size`.  At 256 the bottleneck is 16x16, so its odd blocks
+    shift (decoder_Uformer.py:531-533 only zeroes the shift when the map is one window); the state dict does not change."""
+    from net.model import AirNet
+    with pytest.raises(NotImplementedError):
+        AirNet(make_opt('all3', patch_size=64))           # 4x4 bottleneck under an 8x8 window: fails in the reference too
+    n128, n256 = AirNet(make_opt('all3')), AirNet(make_opt('all3', patch_size=256))
+    assert n128.R.R.bottleneck_0.blocks[1].shift_size == 0 and n256.R.R.bottleneck_0.blocks[1].shift_size == 4
+    assert n128.E.E.encoder_q.uformer.conv.blocks[1].shift_size == 0 and n256.E.E.encoder_q.uformer.conv.blocks[1].shift_size == 4
+    assert [(k, tuple(v.shape)) for k, v in n128.state_dict().items()] == [(k, tuple(v.shape)) for k, v in n256.state_dict().items()]
+
+
 def test_option_defaults(monkeypatch):
     monkeypatch.setattr(sys, 'argv', ['x', '--degradation_embedding_method', 'all_3_bands', '--de_type', 'denoising_25', 'denoising_25'])
     sys.modules.pop('option', None)

@@ -460,7 +460,7 @@ def test_losses_adam_ema():
 
 
 # ------------------------------------------------------------------------------------------------ band decomposition
-@pytest.mark.parametrize('N', [64, 128])
+@pytest.mark.parametrize('N', [64, 128, 256])
 def test_dft_band_decomposition(N):
     from fwair import lfs
     x = rnd(3, N, N)
@@ -569,11 +569,11 @@ def test_moco_logits():
 
 
 # ------------------------------------------------------------------------------------------------ LFS lambda heads
-@pytest.mark.parametrize('nb', [3, 2])
-def test_lfs_lambda_heads(nb):
+@pytest.mark.parametrize('nb,NT', [(3, 64), (2, 64), (3, 256)])      # NT = (S/16)^2 encoder tokens: 64 at 128x128, 256 at 256x256
+def test_lfs_lambda_heads(nb, NT):
     B, C, heads_list = 3, 448, [1, 2, 16]
     nb1 = nb - 1
-    inter = rnd(nb1 * B, 64, C).requires_grad_(True)
+    inter = rnd(nb1 * B, NT, C).requires_grad_(True)
     names = ['mlp_head.%d.0.weight', 'mlp_head.%d.0.bias', 'mlp_head.%d.1.weight', 'mlp_head.%d.1.bias',
              'mlp.%d.0.weight', 'mlp.%d.0.bias', 'mlp.%d.2.weight', 'mlp.%d.2.bias']
     states, dev_p, dev_g = [], [], []
@@ -590,10 +590,10 @@ def test_lfs_lambda_heads(nb):
     # reference: the oracle's per-block lambda head
     lam_ref = []
     for st, h in zip(states, heads_list):
-        lam_ref.append(torch.stack([O.lfs_lambda(st, '', i, inter.view(nb1, B, 64, C)[i - 1])[:, 0] for i in range(1, nb)], 1))
-    xbar, stats = torch.empty(nb1 * B, C, device=DEV), torch.empty(nb1 * B, 64, 2, device=DEV)
+        lam_ref.append(torch.stack([O.lfs_lambda(st, '', i, inter.view(nb1, B, NT, C)[i - 1])[:, 0] for i in range(1, nb)], 1))
+    xbar, stats = torch.empty(nb1 * B, C, device=DEV), torch.empty(nb1 * B, NT, 2, device=DEV)
     idev = inter.detach().to(DEV)
-    call('fw_lfs_xbar', idev, xbar, stats, nb1, B, 64, C, 1e-5)
+    call('fw_lfs_xbar', idev, xbar, stats, nb1, B, NT, C, 1e-5)
     ptab, gtab, keep = [], [], []
     for st, h in zip(states, heads_list):
         for band in (1, 2):
@@ -627,6 +627,6 @@ def test_lfs_lambda_heads(nb):
     call('fw_lfs_lambda_bwd', xbar, ptab, gtab, heads, coef_off, dcoef, save, dxbar, len(heads_list), B, C, nb1)
     for ref_p, p, g in keep:
         close(g, ref_p.grad, 2e-4, 'lambda-head parameter grad')
-    dinter = torch.zeros(nb1 * B, 64, C, device=DEV)
-    call('fw_lfs_xbar_bwd', idev, stats, dxbar, dinter, nb1, B, 64, C)
+    dinter = torch.zeros(nb1 * B, NT, C, device=DEV)
+    call('fw_lfs_xbar_bwd', idev, stats, dxbar, dinter, nb1, B, NT, C)
     close(dinter, inter.grad, 2e-4, 'dinter')

@@ -44,3 +44,31 @@ def test_train_step(variant):
     close(st['E.E.encoder_q.norm.0.0.running_mean'], g['bn_q0_running_mean'], 1e-4, 'bn running mean (q)')
     close(st['E.E.encoder_q.norm.0.0.running_var'], g['bn_q0_running_var'], 1e-4, 'bn running var (q)')
     close(st['E.E.encoder_k.norm.0.0.running_mean'], g['bn_k0_running_mean'], 1e-4, 'bn running mean (k)')
+
+
+def test_256_eval_and_train_step():
+    """Resolution-generic construction: the reference classes built with img_size=256 (golden model256_all3) -- the
+    bottleneck is 16x16 there, so its odd blocks shift, the LFS heads average 256 tokens and the band split is a 256-point DFT."""
+    g = load('model256_all3')
+    st = O.fill_state_seeded(schema('all3'))
+    st['E.E.queue'] = torch.nn.functional.normalize(O.seeded_tensor('E.E.queue', (3, 256, 3)) / 0.02, dim=1)   # K = 3 * batch_size
+    opt = make_opt('all3', batch_size=1, patch_size=256)
+    clean, q, k = synth_batch(1, 256, 'model256.')
+    with torch.no_grad():
+        out = O.airnet_forward(st, opt, q, q, False)
+    close(out, g['restored_eval'], 1e-4, 'restored_eval')
+    assert abs(O.psnr(out, clean) - float(g['psnr_eval'])) < 1e-3
+    names = [str(n) for n in g['grad_names']]
+    for n in names:
+        st[n] = st[n].clone().requires_grad_(True)
+    restored, logits, labels = O.airnet_forward(st, opt, q, k, True)
+    loss, l1, contrast = O.training_loss(opt, restored, logits, labels, clean)
+    close(restored, g['restored_train'], 1e-4, 'restored_train')
+    close(torch.stack(logits), g['logits'], 1e-4, 'logits')
+    close(loss, g['loss'], 1e-5, 'loss')
+    loss.backward()
+    norms = torch.tensor([st[n].grad.norm().item() for n in names])
+    close(norms, g['grad_norms'], 2e-3, 'per-parameter grad norms')
+    for key, val in g.items():
+        if key.startswith('g.'):
+            close(st[key[2:]].grad, val, 2e-3, key)

@@ -53,9 +53,9 @@ def synth_batch(B, size, sigma, seed, device):
     return t(clean), t(noisy()), t(noisy())
 
 
-def make_opt(batch, dtype):
+def make_opt(batch, dtype, patch=128):
     import types
-    return types.SimpleNamespace(L=3, encoder_dim=256, encoder_embed_dim=28, embed_dim=56, batch_size=batch, patch_size=128,
+    return types.SimpleNamespace(L=3, encoder_dim=256, encoder_embed_dim=28, embed_dim=56, batch_size=batch, patch_size=patch,
                                  degradation_embedding_method=['all_3_bands'], encoder_msa_type='freq', contrast_loss_weight=0.6,
                                  encoder_type='Uformer', decoder_type='Uformer', debug_mode=False, frequency_decompose_type='none',
                                  learnable_modulator=False, compute_dtype=dtype, de_type=['denoising_25'] * batch)
@@ -231,6 +231,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--patch-size', type=int, default=128, help='side of the training patch (128 = the headline config; 256 = SURVEY 8f-4)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
@@ -243,10 +244,10 @@ def main():
     torch.cuda.set_device(dev)
     from net.model import AirNet
     torch.manual_seed(1234)
-    opt = make_opt(args.batch, args.dtype)
+    opt = make_opt(args.batch, args.dtype, args.patch_size)
     net = AirNet(opt).to(dev).train()
     eng = E.TrainEngine(net, lr=2e-4, contrast_loss_weight=0.6, use_graph=not args.no_graph)
-    batch = synth_batch(args.batch, 128, 25, 1234 + rank, dev)
+    batch = synth_batch(args.batch, args.patch_size, 25, 1234 + rank, dev)
     clean, xq, xk = batch
     data = (xq, xk, clean)
 
@@ -292,17 +293,17 @@ def main():
     h2d = (time.perf_counter() - t1) / 5
 
     res = {
-        'metric': 'training images/sec @128x128', 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
+        'metric': f'training images/sec @{args.patch_size}x{args.patch_size}', 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: Uformer encoder+decoder (all_3_bands, L=3, freq MSA), denoise sigma=25, '
-                               '128x128, phase-2 train step (fwd+bwd+Adam, DropPath on)', 'per_gpu_batch': args.batch,
+                               f'{args.patch_size}x{args.patch_size}, phase-2 train step (fwd+bwd+Adam, DropPath on)', 'per_gpu_batch': args.batch,
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'hip_graph': graph_ok},
         'loss': {'total': loss[0], 'l1': loss[1], 'contrast': loss[2]},
         'pcie_inclusive_value': round(args.batch * world / (dt / args.steps + h2d), 2), 'h2d_ms_per_step': round(h2d * 1e3, 3),
     }
     peak = PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32_MFMA
-    res['step_mfma_fraction'] = round(ips / world * FLOP_PER_IMAGE_STEP / peak, 5)
+    res['step_mfma_fraction'] = round(ips / world * FLOP_PER_IMAGE_STEP * (args.patch_size / 128) ** 2 / peak, 5)   # FLOPs scale with pixels
     if rank == 0 and world == 1 and not args.no_profile:
         log('timing every distinct GEMM launch of the step (HIP events around captured replays) ...')
         agg, launches = gemm_profile(eng, data)

@@ -93,24 +93,32 @@ def train_loss(restored, clean, logits, w, gscale=1.0):
 # ---------------------------------------------------------------------------------------------------------------
 def _layout(params):
     """Element offset of every parameter in a flat buffer; each starts on a multiple of 8 elements, i.e. 16-byte aligned
-    both in the f32 buffer and in its bf16 shadow (vector loads of biases, GEMM operands)."""
-    offs, o = [], 0
+    both in the f32 buffer and in its bf16 shadow (vector loads of biases, GEMM operands) -- except a tensor marked
+    `_fw_pack` (ordered_parameters), which continues its predecessor with no padding so the group is ONE dense array."""
+    offs, o, end = [], 0, 0
     for p in params:
-        offs.append(o)
-        o += (p.numel() + 7) // 8 * 8
+        start = end if getattr(p, '_fw_pack', False) else o
+        offs.append(start)
+        end = start + p.numel()
+        o = (end + 7) // 8 * 8
     return offs, o
 
 
 def ordered_parameters(root):
     """root.parameters() with each LinearProjection's tensors regrouped as (to_q.weight, to_kv.weight, to_q.bias, to_kv.bias):
     adjacent in a flat buffer they form one [3C, C] weight and one [3C] bias."""
-    from .modules import LinearProjection
+    from .modules import FrequencyWindowAttention, LinearProjection
     group = {}
     for mod in root.modules():
         if isinstance(mod, LinearProjection) and mod.to_q.bias is not None:
             g = [mod.to_q.weight, mod.to_kv.weight, mod.to_q.bias, mod.to_kv.bias]
             for t in g:
                 group[id(t)] = g
+        elif isinstance(mod, FrequencyWindowAttention):
+            # the L*L relative-position tables of one attention (encoder_Uformer.py:216-219) packed back to back: the kernel's
+            # [L*L, 225, heads] operand and its gradient become plain views (no stack forward, no 9 accumulate-adds backward)
+            for t in list(mod.relative_position_bias_table)[1:]:
+                t._fw_pack = True
     out, seen = [], set()
     for p in root.parameters():
         for t in group.get(id(p), [p]):
@@ -245,6 +253,7 @@ class TrainEngine:
                     if p.dim() == 2 and (p.shape[1] * 2) % 16 == 0:
                         p._fw_shadow = sh[o:o + p.numel()].view_as(p)
         self._fuse_projections(net)
+        self._fuse_tables(net)
         moco._ema_hook = self._ema
         self.allreduce = GradAllReducer(self.flat_g, wire_dtype=grad_wire_dtype)
         if dist.is_initialized() and dist.get_world_size() > 1:
@@ -279,6 +288,27 @@ class TrainEngine:
                 if shadow is not None and (K * 2) % 16 == 0:
                     fused['sw'] = shadow[ow:ow + 3 * C * K].view(3 * C, K)
                 mod._fw_fused = fused
+
+    def _fuse_tables(self, net):
+        """Dense [L*L, 225, heads] views over the packed relative-position tables of every FrequencyWindowAttention."""
+        import types
+        from .modules import FrequencyWindowAttention
+        for flat, grad in ((self.flat_p, self.flat_g), (self.flat_k, None)):
+            base = flat.data_ptr()
+            lo, hi = base, base + flat.numel() * 4
+            for mod in net.modules():
+                if not isinstance(mod, FrequencyWindowAttention):
+                    continue
+                tabs = list(mod.relative_position_bias_table)
+                if not (lo <= tabs[0].data_ptr() < hi):
+                    continue
+                n = tabs[0].numel()
+                if any(t.data_ptr() != tabs[0].data_ptr() + i * n * 4 for i, t in enumerate(tabs)):
+                    continue
+                o = (tabs[0].data_ptr() - base) // 4
+                shape = (len(tabs),) + tuple(tabs[0].shape)
+                mod._fw_tab = flat[o:o + len(tabs) * n].view(shape)
+                mod._fw_tab_grad = types.SimpleNamespace(grad=grad[o:o + len(tabs) * n].view(shape)) if grad is not None else None
 
     def set_lr(self, lr):
         self.hyper[0:1].fill_(float(lr))

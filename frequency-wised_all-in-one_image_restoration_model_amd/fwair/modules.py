@@ -389,7 +389,17 @@ class FrequencyWindowAttention(nn.Module):
         self.register_buffer('mask_freq', mf.repeat_interleave(n, 0).repeat_interleave(n, 1)[None, None])
 
     def tables(self):
+        t = getattr(self, '_fw_tab', None)                # engine: the tables lie packed in the flat buffer (TrainEngine._fuse_tables)
+        if t is not None and t.data_ptr() == self.relative_position_bias_table[0].data_ptr():
+            return t
         return torch.stack(list(self.relative_position_bias_table), 0)
+
+    def table_grads(self):
+        """Holder of the dense gradient view the backward kernel accumulates into (engine mode), else None (autograd path)."""
+        t = getattr(self, '_fw_tab', None)
+        if t is not None and t.data_ptr() == self.relative_position_bias_table[0].data_ptr():
+            return getattr(self, '_fw_tab_grad', None)
+        return None
 
 
 class EncLeWinTransformerBlock(nn.Module):
@@ -430,15 +440,15 @@ class EncLeWinTransformerBlock(nn.Module):
         x, xn = Fn.LnResFn.apply(x, self.norm1.weight, self.norm1.bias)
         if self.encoder_msa_type == 'origin':
             geo = (C, nimg, h, h, self.num_heads, 1, 0, self.shift_size, 0)
-            o = Fn.WindowAttnFn.apply(self.attn.qkv(xn), self.attn.tables(), None, geo, None, None)
+            o = Fn.WindowAttnFn.apply(self.attn.qkv(xn), self.attn.tables(), None, geo, self.attn.relative_position_bias_table, None)
             x = Fn.linear(o, self.attn.proj.weight, self.attn.proj.bias, residual=x, rowscale=dp, rows_per_scale=h * h)
         else:
             B = nimg // self.L
             a = self.attn_intra
-            o = Fn.WindowAttnFn.apply(a.qkv(xn), a.tables(), None, (C, B, h, h, self.num_heads, self.L, 0, self.shift_size, 0), None, None)
+            o = Fn.WindowAttnFn.apply(a.qkv(xn), a.tables(), None, (C, B, h, h, self.num_heads, self.L, 0, self.shift_size, 0), a.table_grads(), None)
             y1 = Fn.linear(o, a.proj.weight, a.proj.bias)
             a = self.attn_inter
-            o = Fn.WindowAttnFn.apply(a.qkv(y1), a.tables(), None, (C, B, h, h, self.num_heads, self.L, 1, self.shift_size, 0), None, None)
+            o = Fn.WindowAttnFn.apply(a.qkv(y1), a.tables(), None, (C, B, h, h, self.num_heads, self.L, 1, self.shift_size, 0), a.table_grads(), None)
             x = Fn.linear(o, a.proj.weight, a.proj.bias, residual=x, rowscale=dp, rows_per_scale=h * h)
         x, xn2 = Fn.LnResFn.apply(x, self.norm2.weight, self.norm2.bias)
         return self.mlp.run(xn2, x, dp, nimg)

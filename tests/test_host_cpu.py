@@ -77,6 +77,31 @@ def test_patch_size_sets_the_model_resolution():
     assert [(k, tuple(v.shape)) for k, v in n128.state_dict().items()] == [(k, tuple(v.shape)) for k, v in n256.state_dict().items()]
 
 
+def test_flat_layout_packs_frequency_attention_tables():
+    """engine._layout: every tensor starts 16-byte aligned, except the 2nd..9th relative-position table of a
+    FrequencyWindowAttention, which continue the first so that the kernel operand [L*L, 225, heads] is one dense view."""
+    from net.model import AirNet
+    from fwair import engine as E
+    from fwair.modules import FrequencyWindowAttention
+    enc = AirNet(make_opt('all3')).E.E.encoder_q
+    params = E.ordered_parameters(enc)
+    offs, total = E._layout(params)
+    where = {id(p): o for p, o in zip(params, offs)}
+    assert len(where) == len(list(enc.parameters())) and total % 8 == 0
+    spans = sorted((o, o + p.numel()) for p, o in zip(params, offs))
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))                   # no overlap
+    n = 0
+    for mod in enc.modules():
+        if isinstance(mod, FrequencyWindowAttention):
+            tabs = list(mod.relative_position_bias_table)
+            assert where[id(tabs[0])] % 8 == 0
+            assert [where[id(t)] for t in tabs] == [where[id(tabs[0])] + i * tabs[0].numel() for i in range(len(tabs))]
+            n += 1
+    assert n == 20
+    unpacked = [p for p in params if not getattr(p, '_fw_pack', False)]
+    assert all(where[id(p)] % 8 == 0 for p in unpacked)
+
+
 def test_option_defaults(monkeypatch):
     monkeypatch.setattr(sys, 'argv', ['x', '--degradation_embedding_method', 'all_3_bands', '--de_type', 'denoising_25', 'denoising_25'])
     sys.modules.pop('option', None)

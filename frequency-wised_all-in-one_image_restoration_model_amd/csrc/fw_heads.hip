@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void dft2_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void dft2_band_inv_kernel(const float* __restrict__ fr, const float* __restrict__ fi, const float* __restrict__ mask,
                                                             float* __restrict__ out, int N, int nimg) {
     __shared__ float kr[DFT_SL * DFT_MAXN], ki[DFT_SL * DFT_MAXN], tc[DFT_MAXN], ts[DFT_MAXN];
+    __shared__ int act[DFT_MAXN];                             // column v holds a non-zero of this band's mask
     const int rows = N < DFT_SL ? N : DFT_SL;
     const int n = blockIdx.x, band = blockIdx.y, y0 = blockIdx.z * rows;
     const float* Fr = fr + (size_t)n * N * N; const float* Fi = fi + (size_t)n * N * N;
@@ -73,14 +74,17 @@ __global__ __launch_bounds__(256) void dft2_band_inv_kernel(const float* __restr
     for (int o = threadIdx.x; o < rows * N; o += 256) {       // K[y][v] = sum_u M F[u][v] e^{+i 2pi u y/N}
         const int y = y0 + o / N, v = o % N;
         float ar = 0.f, ai = 0.f;
+        int any = 0;
         for (int u = 0; u < N; ++u) {
             const float m = M[u * N + v];
             if (m == 0.f) continue;
+            any = 1;
             const int k = (u * y) & (N - 1);
             const float c = tc[k], sn = ts[k], a = Fr[u * N + v] * m, b = Fi[u * N + v] * m;
             ar += a * c - b * sn; ai += a * sn + b * c;
         }
         kr[o] = ar; ki[o] = ai;
+        if (o < N) act[v] = any;                                // first row of the slice: one writer per column
     }
     __syncthreads();
     float* o_ = out + ((size_t)band * nimg + n) * N * N + (size_t)y0 * N;
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(256) void dft2_band_inv_kernel(const float* __restr
         const int yl = o / N, xx = o % N;
         float ar = 0.f;
         for (int v = 0; v < N; ++v) {
+            if (!act[v]) continue;                              // uniform over the workgroup: an empty mask column contributes K = 0
             const int k = (v * xx) & (N - 1);
             ar += kr[yl * N + v] * tc[k] - ki[yl * N + v] * ts[k];
         }
@@ -112,6 +117,17 @@ __global__ void dft2_band_spec_kernel(const float* __restrict__ fr, const float*
             out[((size_t)band * nimg + n) * N * N + us * N + vs] = sqrtf(a * a + b * b);
         }
     }
+}
+// last band of a decomposition whose masks partition the spectrum: out[nb-1] = img - sum_{b < nb-1} out[b]   (sum_b M_b = 1)
+__global__ __launch_bounds__(256) void band_residual_kernel(const float* __restrict__ img, float* __restrict__ out, long per_band, int nbands) {
+    const long i = (blockIdx.x * 256L + threadIdx.x) * 4;
+    if (i >= per_band) return;
+    f32x4 r = *reinterpret_cast<const f32x4*>(img + i);
+    for (int b = 0; b + 1 < nbands; ++b) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(out + b * per_band + i);
+        r[0] -= t[0]; r[1] -= t[1]; r[2] -= t[2]; r[3] -= t[3];
+    }
+    *reinterpret_cast<f32x4*>(out + (nbands - 1) * per_band + i) = r;
 }
 // DC split (frequency_decompose_dc): out[0] = mean, out[1] = x - mean
 __global__ __launch_bounds__(256) void dc_split_kernel(const float* __restrict__ img, float* __restrict__ out, int NN, int nimg) {
@@ -439,6 +455,13 @@ extern "C" int fw_dft2_bands(const float* fr, const float* fi, const float* mask
     } else {
         hipLaunchKernelGGL(dft2_band_spec_kernel, dim3(nimg, nbands), dim3(256), 0, ST, fr, fi, mask_unshifted, out, N, nimg, mode - 1);
     }
+    FW_LAUNCH_RET();
+}
+// out: [nbands][nimg][N][N] whose first nbands-1 bands are filled (fw_dft2_bands with nbands-1); img: [nimg][N][N]
+extern "C" int fw_band_residual(const float* img, float* out, int nimg, int N, int nbands, void* stream) {
+    FW_CHECK_ARG(img && out && nimg > 0 && N >= 8 && N % 4 == 0 && nbands >= 2);
+    const long per_band = (long)nimg * N * N;
+    hipLaunchKernelGGL(band_residual_kernel, dim3((unsigned)((per_band / 4 + 255) / 256)), dim3(256), 0, ST, img, out, per_band, nbands);
     FW_LAUNCH_RET();
 }
 extern "C" int fw_dc_split(const float* img, float* out, int nimg, int NN, void* stream) {

@@ -16,7 +16,7 @@ from fwair import lfs
 from fwair.lib import call
 
 
-def _bands(x, mask, mode):
+def _bands(x, mask, mode, partition=False):
     """x: f32 [n, N, N] -> mode 0: Re IDFT2(mask_b * DFT2 x) [nb, n, N, N];  mode 1: (re, im) of mask_b * DFT2 x [nb, n, N, N, 2];
     mode 2: |.| in fftshift-ed coordinates."""
     n, N = x.shape[0], x.shape[1]
@@ -25,7 +25,13 @@ def _bands(x, mask, mode):
     fi = torch.empty_like(fr)
     call('fw_dft2_fwd', x, fr, fi, n, N)
     out = torch.empty((nb, n, N, N, 2) if mode == 1 else (nb, n, N, N), dtype=torch.float32, device=x.device)
-    call('fw_dft2_bands', fr, fi, mask, out, n, N, nb, mode)
+    if mode == 0 and partition and nb >= 2:
+        # the band masks partition the spectrum (sum_b M_b = 1, frequency_decompose.py:47-60), so the band images sum to x:
+        # nb-1 masked inverse transforms, the last (widest) band by subtraction
+        call('fw_dft2_bands', fr, fi, mask, out, n, N, nb - 1, 0)
+        call('fw_band_residual', x, out, n, N, nb)
+    else:
+        call('fw_dft2_bands', fr, fi, mask, out, n, N, nb, mode)
     return out
 
 
@@ -68,6 +74,7 @@ class FrequencyDecompose(nn.Module):
         self.type, self.size, self.h, self.w, self.inverse = type, size, h, w, inverse
         assert size > 0 and size <= 1, 'invalid frequency band width(size=%s)' % (size)
         self._masks = {}
+        self._partition = False
         if self.type in ['frequency_decompose', 'frequency_decompose_1']:
             if h != w or h & (h - 1) or not 8 <= h <= 256:
                 raise NotImplementedError('HIP band decomposition handles square power-of-two maps, 8 <= N <= 256')
@@ -77,6 +84,7 @@ class FrequencyDecompose(nn.Module):
         key = str(device)
         if key not in self._masks:
             m = torch.stack(lfs.band_masks_shifted(self.type, self.size, self.h, self.w)).float()
+            self._partition = bool((m.sum(0) == 1).all())                                        # every frequency in exactly one band
             self._masks[key] = torch.fft.ifftshift(m, dim=(-2, -1)).contiguous().to(device)     # host-built constant
         return self._masks[key]
 
@@ -98,7 +106,7 @@ class FrequencyDecompose(nn.Module):
         mode = 0 if self.inverse is True else 1 if self.inverse is False else 2
         assert self.inverse in (True, False, 'visual')
         xf = x.contiguous().float().reshape(n, N, N)
-        out = _BandsFn.apply(xf, mask, mode) if need_grad else _bands(xf.detach(), mask, mode)
+        out = _BandsFn.apply(xf, mask, mode) if need_grad else _bands(xf.detach(), mask, mode, self._partition)
         out = out.reshape((nb, B, C, N, N, 2) if mode == 1 else (nb, B, C, N, N))
         if mode == 2:
             # the reference's fftshift has no dim argument: it also rolls the batch and channel axes (:32)

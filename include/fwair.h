@@ -137,6 +137,9 @@ int fw_ema(int shadow_dtype, float* pk, const float* pq, void* shadow, long n, f
 int fw_dft2_fwd(const float* img, float* fr, float* fi, int nimg, int N, void* stream);
 int fw_dft2_bands(const float* fr, const float* fi, const float* mask_unshifted, float* out, int nimg, int N, int nbands,
                   int mode, void* stream);
+/* Last band of a decomposition whose masks sum to one: out[nbands-1] = img - sum of the first nbands-1 bands of out
+ * ([nbands][nimg][N][N], filled by fw_dft2_bands called with nbands-1).  Saves one masked inverse transform per image. */
+int fw_band_residual(const float* img, float* out, int nimg, int N, int nbands, void* stream);
 int fw_dc_split(const float* img, float* out, int nimg, int NN, void* stream);
 
 /* ---- encoder contrastive head: BatchNorm2d + LeakyReLU(0.1) + GAP (encoder_Uformer.py:945-951,978-984) -- */

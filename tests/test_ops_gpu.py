@@ -477,6 +477,11 @@ def test_dft_band_decomposition(N):
         call('fw_dft2_bands', fr, fi, mu, out, 3, N, nb, 0)
         ref = O.frequency_decompose(x.view(1, 3, N, N), kind, size, N, N, True)[:, 0]
         close(out, ref, 2e-5, f'{kind} real bands')
+        assert bool((masks.sum(0) == 1).all())                      # the masks partition the spectrum ...
+        outp = torch.full((nb, 3, N, N), float('nan'), device=DEV)  # ... so the last band is x minus the others
+        call('fw_dft2_bands', fr, fi, mu, outp, 3, N, nb - 1, 0)
+        call('fw_band_residual', x.to(DEV), outp, 3, N, nb)
+        close(outp, ref, 2e-5, f'{kind} real bands, last by subtraction')
         out2 = torch.empty(nb, 3, N, N, 2, device=DEV)
         call('fw_dft2_bands', fr, fi, mu, out2, 3, N, nb, 1)
         ref2 = O.frequency_decompose(x.view(1, 3, N, N).double(), kind, size, N, N, False)[:, 0]

@@ -468,6 +468,7 @@ class TrainEngine:
         if g2 is not None:
             self.allreduce(self.n_enc)
             g2.replay()
+        Fn.config.shadow_epoch += 1
         return out
 
     def step_eager(self, xq, xk, clean):
@@ -544,12 +545,14 @@ class TrainEngine:
             wb = self.allreduce.launch(0, self.n_enc)
             GradAllReducer.finish(wa); GradAllReducer.finish(wb)
             gc.replay()
+            Fn.config.shadow_epoch += 1                      # the replay changed the weights behind functional.shadow()'s stamps
             self.last = self._out
             return self._out
         self._g1.replay()
         if self._g2 is not None:
             self.allreduce()
             self._g2.replay()
+        Fn.config.shadow_epoch += 1
         self.last = self._out
         return self._out
 

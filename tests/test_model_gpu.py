@@ -151,6 +151,27 @@ def test_engine_two_stage_backward_matches_single_pass():
     assert float((pb - pa).abs().median()) < 1e-7 and float(((pb - pa).abs() > 1e-5).float().mean()) < 0.02, 'parameters after 2 Adam steps'
 
 
+def test_eval_after_graph_replayed_steps_sees_current_weights():
+    """A captured step changes the weights without running any Python, so the on-demand re-laid-out weight copies of
+    functional.shadow() (depthwise taps, k4 / transposed conv weights, narrow rows) must not be trusted across a replay: an
+    eval forward right after training equals the same forward with every cached copy invalidated by hand."""
+    from fwair import engine as E
+    from fwair import functional as Fn
+    net, opt = build('all3', 'bf16')
+    net.train()
+    eng = E.TrainEngine(net, lr=1e-2, contrast_loss_weight=0.6, use_graph=True)      # large steps: stale copies would show
+    clean, q, k = synth_batch(2, 128, 'stale.')
+    for _ in range(3):
+        eng.step(q.to(DEV), k.to(DEV), clean.to(DEV))
+    net.eval()
+    with torch.no_grad():
+        a = net(x_query=q.to(DEV), x_key=q.to(DEV)).clone()
+        Fn.config.shadow_epoch += 1
+        b = net(x_query=q.to(DEV), x_key=q.to(DEV))
+    Fn.config.direct_grads = False
+    assert torch.equal(a, b)
+
+
 def test_256_resolution_fp32_and_bf16():
     """Resolution-generic construction: `opt.patch_size=256` through the unchanged seam, against the golden made by
     the reference's classes with img_size=256 (16x16 bottleneck with shifted odd blocks, 256-token LFS heads, 256-point band DFT)."""

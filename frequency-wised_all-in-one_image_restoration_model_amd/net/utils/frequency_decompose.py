@@ -5,7 +5,7 @@ instead of torch.fft.  Same constructor, same output shapes:
     'frequency_decompose_1' DC, (0,s] ... (1-s,1]            -> [nb+1, B, C, h, w]
     'frequency_decompose_dc' mean / residual                 -> [2,    B, C, h, w]
     inverse=False -> [..., 2] (re, im) of the masked, un-shifted spectrum;  inverse='visual' -> magnitudes.
-Square power-of-two maps up to 128x128 (what the model uses); anything else raises NotImplementedError.
+Square power-of-two maps up to 256x256 (the model uses 128, or 256 with --patch_size 256); anything else raises NotImplementedError.
 """
 import math
 

@@ -3,6 +3,8 @@ synthesis on the uint8 grid, two independent random crops of the same degraded i
 utils/image_utils.py:133-160 per crop -- as batched tensor ops, so that it runs on the GPU next to the model instead of in
 DataLoader workers.  Images are channels-first ([..., C, H, W]); the reference's numpy code is HWC (flipud = flip H,
 rot90 = counter-clockwise in the H-W plane), which maps to dims (-2, -1) here."""
+import math
+
 import torch
 
 
@@ -18,8 +20,59 @@ def augment(x, mode):
 def add_noise(clean_u8, sigma, generator=None):
     """dataset_utils.py:126: clip(gt + randn * sigma, 0, 255).astype(uint8).  clean_u8: uint8 or float tensor on the 0..255 grid."""
     g = clean_u8.float()
-    n = torch.randn(g.shape, device=g.device, generator=generator)
+    if generator is not None and generator.device != g.device:      # a host generator driving device data: draw there, move
+        n = torch.randn(g.shape, device=generator.device, generator=generator).to(g.device)
+    else:
+        n = torch.randn(g.shape, device=g.device, generator=generator)
     return (g + n * float(sigma)).clamp_(0, 255).to(torch.uint8)          # float -> uint8 truncates, like numpy's astype
+
+
+def add_rain(clean_u8, generator=None, streaks=None, length=None, angle_deg=None, strength=0.7):
+    """Synthetic stand-in for the rain pairs the reference only loads from disk (dataset_utils.py:93-95,129):
+    additive bright line streaks at 45 +- 15 degrees, drawn as `length` shifted copies of a sparse seed map.  uint8 in / out."""
+    g = clean_u8.float()
+    H, W = g.shape[-2:]
+    dev = g.device
+    rnd = lambda *shape: torch.rand(shape, generator=generator, device='cpu')
+    ang = float(angle_deg) if angle_deg is not None else 30.0 + 30.0 * float(rnd(1))
+    n = int(streaks) if streaks is not None else max(1, H * W // 400)
+    L = int(length) if length is not None else max(4, H // 8)
+    ys = (rnd(n) * H).long().clamp_(max=H - 1)
+    xs = (rnd(n) * W).long().clamp_(max=W - 1)
+    seed = torch.zeros((H, W), dtype=torch.float32)
+    seed[ys, xs] = 0.5 + 0.5 * rnd(n)
+    seed = seed.to(dev)
+    dy, dx = math.sin(math.radians(ang)), math.cos(math.radians(ang))
+    layer = torch.zeros((H, W), dtype=torch.float32, device=dev)
+    for t in range(L):                                     # a streak = the seed pixel smeared along (dy, dx), fading towards its tail
+        layer = torch.maximum(layer, torch.roll(seed, shifts=(int(round(t * dy)), int(round(t * dx))), dims=(0, 1)) * (1.0 - t / L))
+    return (g + 255.0 * strength * layer).clamp_(0, 255).to(torch.uint8)
+
+
+def add_haze(clean_u8, generator=None, beta=None, airlight=0.8):
+    """Synthetic stand-in for the haze pairs: I = J t + A (1 - t), t = exp(-beta * depth), depth = a vertical ramp
+    (far at the top of the frame), A = 0.8.  uint8 in / out."""
+    g = clean_u8.float() / 255.0
+    H = g.shape[-2]
+    b = float(beta) if beta is not None else 0.6 + 1.2 * float(torch.rand((1,), generator=generator, device='cpu'))
+    depth = torch.linspace(1.0, 0.1, H, device=g.device).view(H, 1)
+    t = torch.exp(-b * depth)
+    return ((g * t + airlight * (1.0 - t)) * 255.0).clamp_(0, 255).to(torch.uint8)
+
+
+def degrade(clean_u8, task, generator=None):
+    """The degraded image of one `--de_type` entry.  denoising_<sigma> as dataset_utils.py:123-126 (sigma 0 = a random choice of
+    15 / 25 / 50); deraining / dehazing: the synthetic stand-ins above (the reference reads those pairs from disk)."""
+    if task.startswith('denoising'):
+        sigma = int(task.split('_')[-1])
+        if sigma == 0:
+            sigma = (15, 25, 50)[int(torch.randint(0, 3, (1,), generator=generator, device='cpu'))]
+        return add_noise(clean_u8, sigma, generator)
+    if task == 'deraining':
+        return add_rain(clean_u8, generator)
+    if task == 'dehazing':
+        return add_haze(clean_u8, generator)
+    raise ValueError(f'unknown de_type {task!r}')
 
 
 def crop_pair(degraded, clean, size, generator=None):
@@ -46,6 +99,12 @@ def training_pair(clean_u8, size, sigma=None, degraded_u8=None, generator=None):
 
 
 def training_batch(images_u8, size, sigmas, generator=None):
-    """A batch: images_u8 = list of [3, H, W] uint8 device tensors (sizes may differ), sigmas = one noise level per image."""
-    items = [training_pair(img, size, sigma=s, generator=generator) for img, s in zip(images_u8, sigmas)]
+    """A batch: images_u8 = list of [3, H, W] uint8 device tensors (sizes may differ); sigmas = per image a noise level, or a
+    `--de_type` name ('denoising_25', 'deraining', 'dehazing': the dataset cycles its tasks item by item, dataset_utils.py:99)."""
+    items = []
+    for img, s in zip(images_u8, sigmas):
+        if isinstance(s, str):
+            items.append(training_pair(img, size, degraded_u8=degrade(img, s, generator), generator=generator))
+        else:
+            items.append(training_pair(img, size, sigma=s, generator=generator))
     return tuple(torch.stack(t, 0) for t in zip(*items))

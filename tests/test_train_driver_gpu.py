@@ -51,3 +51,13 @@ def test_frequency_l1_term(tmp_path):
     la = float(re.search(r'l1_loss:(\d+\.\d+)', open(out + 'a/train.log').read()).group(1))
     lb = float(re.search(r'l1_loss:(\d+\.\d+)', open(out + 'b/train.log').read()).group(1))
     assert lb > la > 0 and lb < 100 * la + 10, (la, lb)
+
+
+def test_mixed_degradation_batches(tmp_path):
+    """BASELINE configs[2]: `--de_type` with several tasks -- every sample of a batch carries the next task in turn
+    (dataset_utils.py:99), rain / haze from the synthetic stand-ins of fwair/augment.py."""
+    out = str(tmp_path) + '/'
+    run(out, '--epochs', '1', '--epochs_encoder', '0', '--per_gpu_batch', '3', '--de_type', 'denoising_15', 'deraining', 'dehazing')
+    line = open(out + 'train.log').read().splitlines()[0]
+    m = re.fullmatch(r'Epoch \(0\)  Loss: l1_loss:(\d+\.\d{4}) contrast_loss:(\d+\.\d{4})', line)
+    assert m and 0 < float(m.group(1)) < 1 and 0 < float(m.group(2)) < 20

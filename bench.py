@@ -19,6 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, 'frequency-wised_all-in-one_image_restoration_model_amd')
 sys.path.insert(0, PKG)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL across processes needs it on this driver
 
 import numpy as np          # noqa: E402
 import torch                # noqa: E402

@@ -29,6 +29,7 @@ _own.add_argument('--no_graph', action='store_true', help='eager launches instea
 _ARGS, _rest = _own.parse_known_args()
 sys.argv = [sys.argv[0]] + _rest                       # option.py parses sys.argv at import (reference option.py:3)
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL across processes needs it on this driver
 import torch                                            # noqa: E402
 
 from fwair import engine as E                           # noqa: E402

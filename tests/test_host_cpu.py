@@ -134,6 +134,17 @@ def test_synthetic_rain_haze_and_mixed_task_batches():
     assert b[0].shape == (2, 3, 16, 16) and float((b[0][0] - b[2][0]).min()) >= 0
 
 
+def test_c_abi_header_is_plain_c():
+    """include/fwair.h is the drop-in boundary: it must compile as C99 (no torch / C++ types in the signatures) and as C++."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, 'include', 'fwair.h')
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only', '-x', 'c', hdr], check=True)
+    subprocess.run(['g++', '-std=c++17', '-fsyntax-only', '-x', 'c++', hdr], check=True)
+
+
 def test_option_defaults(monkeypatch):
     monkeypatch.setattr(sys, 'argv', ['x', '--degradation_embedding_method', 'all_3_bands', '--de_type', 'denoising_25', 'denoising_25'])
     sys.modules.pop('option', None)

@@ -31,12 +31,18 @@ def _worker(rank, world, port, wire, out):
     x, y = torch.randn(8, 12), torch.randn(8, 5)
     xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
     red = GradAllReducer(g, bucket_elems=200, wire_dtype=wire)          # several buckets
-    for _ in range(2):                                                  # second pass checks zero + re-accumulate
+    for it in range(2):                                                 # second pass checks zero + re-accumulate
         g.zero_()
         loss = torch.nn.functional.l1_loss(net(xs), ys) / world         # pre-scaled by 1/world
         loss.backward()
         assert params[0].grad.data_ptr() == g.data_ptr()                # autograd accumulated in place
-        red()
+        if it == 0:
+            red()
+        else:                                                           # the two-stage form of the engine: tail range first, head range after
+            cut = 136
+            wa = red.launch(cut, g.numel())
+            wb = red.launch(0, cut)
+            GradAllReducer.finish(wa); GradAllReducer.finish(wb)
     if rank == 0:
         torch.save(torch.cat([p.grad.reshape(-1) for p in params]), out)      # per-parameter views (the flat buffer is padded)
     dist.destroy_process_group()

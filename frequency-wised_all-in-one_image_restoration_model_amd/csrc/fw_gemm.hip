@@ -793,6 +793,12 @@ int dispatch_trans(const GemmArgs& a, int xt, int wt, hipStream_t st) {
 }  // namespace
 
 // C-ABI.  Declared in include/fwair.h.
+// Which kernel the last fw_gemm call of this thread was dispatched to (measurement aid: bench.py labels its per-launch timings
+// with it so that they line up with the rocprofv3 kernel names): family * 100000 + BN * 100 + xT * 10 + wT,
+// family 0 = gemm_kernel (BN = 64 / 128), 1 = gemm_tr_kernel, 2 = gemm_stream_kernel.
+static thread_local int g_last_variant = 0;
+extern "C" int fw_gemm_last_variant(void) { return g_last_variant; }
+
 extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op, const void* W, long ldw,
                        int w_trans, int w_op, void* C, long ldc, int out_f32, int accumulate, int M, int N,
                        int K, float alpha, const float* bias, int act, float slope, const void* aux,
@@ -835,18 +841,23 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
     // tall-skinny products stream X past a W panel held in LDS (gemm_stream_kernel)
     static const long stream_min_m = getenv("FW_GEMM_STREAM_MIN_M") ? atol(getenv("FW_GEMM_STREAM_MIN_M")) : 32768;
     if (!x_trans && splitk == 1 && !accumulate && x_op == 0 && w_op == 0 && !xsum && K * sz <= 512 && M >= stream_min_m) {
+        g_last_variant = 200000 + (w_trans ? 1 : 0);
         return dtype == FW_DT_BF16 ? dispatch_stream<bf16raw>(a, w_trans, st) : dispatch_stream<float>(a, w_trans, st);
     }
     // bf16 products whose W is stored [K][N] (weight gradients: X token-major too; input gradients: X k-contiguous), whole
     // 64-deep K steps: W (and X) tiles go to LDS as they are and are read with transposing LDS reads (gemm_tr_kernel)
     static const int use_tr = getenv("FW_GEMM_TR") ? atoi(getenv("FW_GEMM_TR")) : 3;
     if (dtype == FW_DT_BF16 && w_trans && x_op == 0 && w_op == 0 && N > 64 && K % 64 == 0 && a.kper % 64 == 0 && ldw % 8 == 0) {
-        if (x_trans && (use_tr & 1) && ldx % 8 == 0) return launch_tr<true>(a, st);
+        if (x_trans && (use_tr & 1) && ldx % 8 == 0) { g_last_variant = 100011; return launch_tr<true>(a, st); }
         static const long tr_min_tiles = getenv("FW_GEMM_TR_MIN_TILES") ? atol(getenv("FW_GEMM_TR_MIN_TILES")) : 384;
-        if (!x_trans && (use_tr & 2) && !xsum && (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk >= tr_min_tiles) return launch_tr<false>(a, st);
+        if (!x_trans && (use_tr & 2) && !xsum && (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk >= tr_min_tiles) {
+            g_last_variant = 100001;
+            return launch_tr<false>(a, st);
+        }
     }
     // 128x64 tiles when N is narrow or when 128x128 tiles would leave most of the 256 CUs (2 blocks each) idle
     const bool small_n = N <= 64 || (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk < 384;
+    g_last_variant = (small_n ? 64 : 128) * 100 + (x_trans ? 10 : 0) + (w_trans ? 1 : 0);
     if (dtype == FW_DT_BF16) {
         return small_n ? dispatch_trans<bf16raw, 64>(a, x_trans, w_trans, st)
                        : dispatch_trans<bf16raw, 128>(a, x_trans, w_trans, st);

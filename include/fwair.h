@@ -35,6 +35,10 @@ int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op, const voi
             void* C, long ldc, int out_f32, int accumulate, int M, int N, int K, float alpha, const float* bias, int act,
             float slope, const void* aux, long ldaux, const float* rowscale, int rows_per_scale, const float* residual,
             long ldr, int splitk, void* C2, long ldc2, float* xsum, long c_zstride, long xsum_zstride, void* stream);
+/* Measurement aid: the kernel the calling thread's last fw_gemm was dispatched to, as
+ * family * 100000 + BN * 100 + x_trans * 10 + w_trans  (family 0 gemm_kernel, 1 gemm_tr_kernel, 2 gemm_stream_kernel). */
+int fw_gemm_last_variant(void);
+
 /* split-K without atomics: slice z stores its partial tile at C + z*c_zstride (and xsum + z*xsum_zstride); this sums the slices */
 int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, float* dst2, long off2, long n2,
                    void* stream);

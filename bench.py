@@ -147,76 +147,234 @@ def gemm_profile(engine, batch, reps=8):
         dt = e0.elapsed_time(e1) * 1e-3 / reps
         sz = x.element_size()
         sk = max(1, int(kw.get('splitk', 1) or 1))
-        by = (M * K + N * K) * sz + M * N * kw['out'].element_size() * sk
+        # STRICT algorithmic bytes: every operand and the result touched ONCE -- X + W + C (+ the fused epilogue's own
+        # operands: residual / GELU' argument read, GELU twin written).  The implementation's split-K partial slabs
+        # ((sk - 1) extra copies of C, re-read by the slab fold) and the read-modify-write of an accumulating C are
+        # OVERHEAD, tallied separately and never credited to `achieved`.
+        by = (M * K + N * K) * sz + M * N * kw['out'].element_size()
+        over = M * N * kw['out'].element_size() * (2 * sk - 1 if sk > 1 else 0)   # (sk-1) extra slab writes + sk slab reads of the fold
         if kw.get('accumulate'):
-            by += M * N * kw['out'].element_size()
+            over += M * N * kw['out'].element_size()
         for key in ('residual', 'aux', 'out_gelu'):
             if kw.get(key) is not None:
                 by += M * N * kw[key].element_size()
         fam, bn, xt, wt = code // 100000, code // 100 % 1000, bool(code // 10 % 10), bool(code % 10)
         variant = ('bf16' if x.dtype == torch.bfloat16 else 'f32', ('stream', 'tr')[2 - fam] if fam else bn, xt, wt)
-        out.append((variant, (M, N, K, sk), cnt, 2.0 * M * N * K, float(by), dt))
+        out.append((variant, (M, N, K, sk), cnt, 2.0 * M * N * K, float(by), dt, float(over)))
         del g, sets, kw, x, w
     agg = {}
-    for variant, shape, cnt, fl, by, dt in out:
-        d = agg.setdefault(variant, [0.0, 0.0, 0, 0.0, 0.0])
+    for variant, shape, cnt, fl, by, dt, over in out:
+        d = agg.setdefault(variant, [0.0, 0.0, 0, 0.0, 0.0, 0.0])
         d[0] += fl * cnt; d[1] += dt * cnt; d[2] += cnt; d[3] += by * cnt
         d[4] += cnt * max(fl / PEAK_FOR[variant[0]], by / PEAK_HBM)          # time the launches would take at their roofline
+        d[5] += over * cnt
     dump = os.environ.get('FW_GEMM_DUMP')
     if dump:
         with open(dump, 'w') as f:
             f.write('dtype,kernel,xT,wT,M,N,K,splitk,launches_per_step,us_per_launch,ms_per_step,TFLOPs,GBs,roofline_us\n')
-            for v, sh, cnt, fl, by, dt in sorted(out, key=lambda r: -r[2] * r[5]):
+            for v, sh, cnt, fl, by, dt, _ in sorted(out, key=lambda r: -r[2] * r[5]):
                 roof = max(fl / PEAK_FOR[v[0]], by / PEAK_HBM) * 1e6
                 f.write(f'{v[0]},{v[1]},{int(v[2])},{int(v[3])},{sh[0]},{sh[1]},{sh[2]},{sh[3]},{cnt},{dt * 1e6:.1f},'
                         f'{dt * cnt * 1e3:.3f},{fl / dt / 1e12:.1f},{by / dt / 1e9:.0f},{roof:.1f}\n')
     return agg, len(rec)
 
 
+PMC_FILE = 'r02_pmc_traffic.json'
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2 -- the gfx950
-    correction of MI355X_MICROARCH.md -- plus WRITE_SIZE, two separate --pmc runs of this same bench command; summarised by
-    tools/pmc_summary.py).  None when no measurement for this kernel is on file."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    """-> (HBM bytes per launch of `kernel`, provenance) from the rocprofv3 PMC passes committed under profiles/: FETCH_SIZE x 2
+    (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, two SEPARATE --pmc runs of this same bench command,
+    summarised by tools/pmc_summary.py (which refuses a missing pass).  Counters cannot be read from inside this process, so
+    the figure is the one on file -- its commit and date travel with it; (None, None) when the file has no complete
+    (read AND write) measurement of this kernel."""
+    path = os.path.join(ROOT, 'profiles', PMC_FILE)
     try:
         with open(path) as f:
-            return json.load(f).get(kernel, {}).get('hbm_bytes_per_launch')
+            doc = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, None
+    ent = doc.get('kernels', {}).get(kernel)
+    if not ent or not ent.get('write_kib_per_launch') or not ent.get('fetch_kib_raw_per_launch'):
+        return None, None
+    return ent['hbm_bytes_per_launch'], {'file': 'profiles/' + PMC_FILE, 'commit': doc.get('commit'), 'collected': doc.get('collected'),
+                                         'fetch_bytes': int(2048 * ent['fetch_kib_raw_per_launch']),
+                                         'write_bytes': int(1024 * ent['write_kib_per_launch'])}
+
+
+def attn_profile(engine, batch, reps=4):
+    """Per-launch GPU time of every distinct window-attention launch of one training step (the W-MSA kernels of the
+    north star), measured like gemm_profile: signatures recorded during one eager step, then `reps` launches -- each on
+    its OWN operands -- inside a captured HIP graph, HIP events on the capture stream.
+
+    Counted FLOPs: 4*64*64*D per (window, head, key tile) forward -- QK^T and AV only; softmax, the
+    relative-position bias and the learned-frequency-selection filter are NOT counted -- and twice that backward.
+    Algorithmic bytes: q, k, v read once and the output + log-sum-exp written once per item forward; q, k, v, dO (and O for
+    the two-key-tile encoder form) read, dq, dk, dv written backward."""
+    from fwair import functional as Fn
+    from fwair import ops
+    from fwair.lib import call as real_call, dt as dtc
+    rec = []
+
+    def spy(name, *a):
+        if name in ('fw_attn_fwd', 'fw_attn_bwd'):
+            if name == 'fw_attn_fwd':
+                (dty, D, nkt, lfs), ld, (B, H, W, heads, L, mode, shift) = a[:4], a[7], a[14:21]
+            else:
+                (dty, D, nkt, lfs), ld, (B, H, W, heads, L, mode, shift) = a[:4], a[7], a[24:31]
+            rec.append((name, dty, D, nkt, lfs, int(ld), B, H, W, heads, L, mode, shift))
+        return real_call(name, *a)
+
+    Fn.call = spy
+    try:
+        engine.step_eager(*batch)
+        torch.cuda.synchronize()
+    finally:
+        Fn.call = real_call
+    counts = {}
+    for sig in rec:
+        counts[sig] = counts.get(sig, 0) + 1
+    side = torch.cuda.Stream()
+    rows_out = []
+    for sig, cnt in counts.items():
+        name, dty, D, nkt, lfs, ld, B, H, W, heads, L, mode, shift = sig
+        tdt = torch.bfloat16 if dty == 1 else torch.float32
+        sz = 2 if dty == 1 else 4
+        C = heads * D
+        Cp = (C + 7) // 8 * 8
+        rows = L * B * H * W
+        items = B * (H // 8) * (W // 8) * L * heads
+        ntab = L * L if L > 1 else 1
+
+        def operands():
+            qkv = (torch.randn(rows, ld, device='cuda') * 0.5).to(tdt)
+            tables = torch.randn(ntab, 225, heads, device='cuda') * 0.2
+            coef = None
+            if lfs:
+                coef = torch.tensor([1.1, -0.1 / 64, 0.2], device='cuda').repeat(B, heads, 1).contiguous()
+            tab = ops._lfs.device_table(tdt, qkv.device) if lfs == 2 else None
+            out = Fn.act_empty(rows, C, tdt, qkv.device)
+            lse = torch.empty((items, 64), dtype=torch.float32, device='cuda')
+            dout = Fn.act_empty(rows, C, tdt, qkv.device)
+            dout.copy_((torch.randn(rows, C, device='cuda') * 0.1).to(tdt))
+            dqkv = Fn.act_empty(rows, qkv.shape[1], tdt, qkv.device)
+            d2 = Fn.act_empty(rows, qkv.shape[1], tdt, qkv.device) if nkt == 2 else None
+            dtab = torch.zeros_like(tables)
+            dcoef = torch.zeros_like(coef) if coef is not None else None
+            return qkv, tables, coef, tab, out, lse, dout, dqkv, d2, dtab, dcoef
+
+        def fwd(o):
+            qkv, tables, coef, tab, out, lse = o[:6]
+            real_call('fw_attn_fwd', dty, D, nkt, lfs, qkv, qkv[:, Cp:], qkv[:, Cp + C:], qkv.stride(0), out, out.stride(0), lse, tables,
+                      coef, tab, B, H, W, heads, L, mode, shift, float(D) ** -0.5)
+
+        def bwd(o):
+            qkv, tables, coef, tab, out, lse, dout, dqkv, d2, dtab, dcoef = o
+            real_call('fw_attn_bwd', dty, D, nkt, lfs, qkv, qkv[:, Cp:], qkv[:, Cp + C:], qkv.stride(0), out, out.stride(0), dout,
+                      dout.stride(0), lse, tables, coef, tab, dqkv, dqkv[:, Cp:], dqkv[:, Cp + C:],
+                      d2[:, Cp:] if d2 is not None else None, d2[:, Cp + C:] if d2 is not None else None, dqkv.stride(0), dtab, dcoef,
+                      B, H, W, heads, L, mode, shift, float(D) ** -0.5)
+
+        sets = [operands() for _ in range(reps)]
+        run = fwd if name == 'fw_attn_fwd' else bwd
+        with torch.cuda.stream(side):
+            for o in sets:
+                fwd(o)                                        # the backward needs a real forward (O, LSE) behind it
+            run(sets[0])
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                for o in sets:
+                    run(o)
+            g.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            g.replay()
+            e1.record(side)
+            torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / reps
+        tile = items * 64 * D * sz                           # bytes of one [items][64][D] operand
+        if name == 'fw_attn_fwd':
+            fl = 4.0 * 64 * 64 * D * items * nkt
+            by = tile * (1 + 2 * nkt) + tile + items * 64 * 4
+        else:
+            fl = 8.0 * 64 * 64 * D * items * nkt
+            by = tile * (2 + 2 * nkt) + (tile if nkt > 1 else 0) + items * 64 * 4 + tile * (1 + 2 * nkt)
+        kind = ('decoder' if L == 1 and D == 56 else 'encoder') + ('+lfs' if lfs == 2 else '+affine' if lfs == 1 else '')
+        rows_out.append((kind, 'fwd' if name == 'fw_attn_fwd' else 'bwd', sig, cnt, fl, by, t))
+        del g, sets
+    return rows_out
+
+
+def wmsa_block(rows, peak):
+    """Aggregate attn_profile rows -> {kernel family: {fwd, bwd: time, counted TFLOP/s, MFMA fraction, GB/s, HBM fraction}}."""
+    out = {}
+    for kind, way, sig, cnt, fl, by, t in rows:
+        d = out.setdefault(kind, {}).setdefault(way, [0.0, 0.0, 0.0, 0])
+        d[0] += fl * cnt; d[1] += by * cnt; d[2] += t * cnt; d[3] += cnt
+    res = {}
+    for kind, ways in out.items():
+        res[kind] = {}
+        for way, (fl, by, t, cnt) in ways.items():
+            res[kind][way] = {'launches_per_step': cnt, 'ms_per_step': round(t * 1e3, 3), 'counted_tflops': round(fl / t / 1e12, 2),
+                              'mfma_frac': round(fl / t / peak, 5), 'algorithmic_gbs': round(by / t / 1e9, 1),
+                              'hbm_frac': round(by / t / PEAK_HBM, 4)}
+    return res
+
+
+def allinone_batch(B, size, seed):
+    """BASELINE configs[2] / SURVEY 8(d) config 3: denoise sigma 15 / 25 / 50, derain, dehaze cycled over the batch (the rain
+    and haze pairs are the synthetic stand-ins of fwair/augment.py; the reference only reads them from disk)."""
+    from fwair import augment as A
+    clean, _, _ = synth_batch(B, size, 25, seed, 'cpu')
+    tasks = ['denoising_15', 'denoising_25', 'denoising_50', 'deraining', 'dehazing']
+    g = torch.Generator().manual_seed(seed)
+    cu8 = (clean * 255).round().to(torch.uint8)
+    q = torch.stack([A.degrade(cu8[i], tasks[i % 5], g).float() / 255 for i in range(B)])
+    k = torch.stack([A.degrade(cu8[i], tasks[i % 5], g).float() / 255 for i in range(B)])
+    return clean, q, k
 
 
 def cpu_baseline(threads):
-    """The CPU oracle (oracle/airnet_oracle.py, the fp32 restatement pinned against the reference) timed on the host
-    cores: phase-2 steps (forward + backward + Adam) at B = 2, 128x128 -- a bounded sample of the same workload."""
+    """The CPU oracle (oracle/airnet_oracle.py, the fp32 restatement pinned against the reference) timed on the host cores as
+    SURVEY.md 8(d) / BASELINE.md section 3 prescribe: the all-in-one batch B = 5 (denoise 15 / 25 / 50, derain, dehaze), 128x128,
+    phase-2 steps (forward + backward + Adam lr 2e-4), 1 warm-up + 3 timed steps.  A progress line after every step."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import airnet_oracle as O
     from helpers import schema
     torch.set_num_threads(threads)
-    log(f'cpu baseline: oracle train steps on {threads} threads')
-    B = 2
+    cpu = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu = next((ln.split(':', 1)[1].strip() for ln in f if ln.startswith('model name')), cpu)
+    except OSError:
+        pass
+    B, warm, timed = 5, 1, 3
+    log(f'cpu baseline: oracle train steps, B={B}, on {threads} threads of {cpu}')
     opt = O.make_opt(batch_size=B)
     st = O.fill_state_seeded(schema('all3'))
+    st['E.E.queue'] = torch.nn.functional.normalize(O.seeded_tensor('E.E.queue', (3, 256, 3 * B)) / 0.02, dim=1)
     names = [k for k in st if st[k] is not None and st[k].is_floating_point() and O.is_parameter_key(k) and not k.startswith('E.E.encoder_k.')]
     for n in names:
         st[n] = st[n].clone().requires_grad_(True)
     optim = torch.optim.Adam([st[n] for n in names], lr=2e-4)
-    clean, q, k = (t.cpu() for t in synth_batch(B, 128, 25, 99, 'cpu'))
+    clean, q, k = allinone_batch(B, 128, 99)
     t0 = time.time()
-    steps = 0
-    while steps < 2:
+    for step in range(warm + timed):
+        if step == warm:
+            t0 = time.time()           # the first step is warm-up (allocator, thread pools)
+        t1 = time.time()
         optim.zero_grad()
         restored, logits, labels = O.airnet_forward(st, opt, q, k, True)
         loss, _, _ = O.training_loss(opt, restored, logits, labels, clean)
         loss.backward()
         optim.step()
-        steps += 1
-        log(f'cpu baseline: step {steps} done at {time.time() - t0:.1f}s')
-        if steps == 1:
-            t0 = time.time()           # first step = warm-up (allocator, thread pools)
+        log(f'cpu baseline: step {step + 1}/{warm + timed} took {time.time() - t1:.1f}s (loss {float(loss):.4f})')
     dt = time.time() - t0
-    return {'value': round(B * (steps - 1) / dt, 4), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'{steps - 1} phase-2 train step(s) (fwd+bwd+Adam) of the CPU oracle, B={B}, 128x128, fp32, after 1 warm-up step'}
+    return {'value': round(B * timed / dt, 4), 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'cpu_model': cpu,
+            'sample': f'{timed} phase-2 train steps (fwd+bwd+Adam) of the CPU oracle on the all-in-one batch B={B} '
+                      f'(denoise 15/25/50, derain, dehaze), 128x128, fp32, after {warm} warm-up step'}
 
 
 def log(msg):
@@ -317,21 +475,39 @@ def main():
         agg, launches = gemm_profile(eng, data)
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         tot_t = sum(v[1] for v in agg.values())
-        v, (fl, tt, cnt, by, troof) = dom
+        v, (fl, tt, cnt, by, troof, over) = dom
         # the variant's launches are priced one by one against max(FLOPs / MFMA peak, bytes / HBM peak); `bound` is the
         # side that sets most of that time, `achieved` / `peak` are quoted in its unit, `frac` = roofline time / measured
         hbm = by / PEAK_HBM > fl / peak
         kname = (f'gemm_stream_kernel<{v[0]},wT={int(v[3])}>' if v[1] == 'stream' else f'gemm_tr_kernel<xT={int(v[2])}>' if v[1] == 'tr'
                  else f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>')
+        traffic, prov = pmc_traffic(kname)
+        ach = (by / tt / 1e9) if hbm else (fl / tt / 1e12)
+        pk = (PEAK_HBM / 1e9) if hbm else (peak / 1e12)
         res['roofline'] = {'bound': 'hbm' if hbm else 'mfma', 'kernel': kname,
-                           'achieved': round((by / tt / 1e9) if hbm else (fl / tt / 1e12), 2),
-                           'peak': (PEAK_HBM / 1e9) if hbm else (peak / 1e12), 'unit': 'GB/s' if hbm else 'TFLOP/s',
-                           'frac': round(troof / tt, 5), 'traffic': pmc_traffic(kname), 'avg_launch_us': round(tt / cnt * 1e6, 2),
-                           'tflops': round(fl / tt / 1e12, 2), 'algorithmic_gbs': round(by / tt / 1e9, 1),
+                           'achieved': round(ach, 2), 'peak': pk, 'unit': 'GB/s' if hbm else 'TFLOP/s',
+                           'frac': round(ach / pk, 5),                        # = achieved / peak, strict algorithmic bytes (X + W + C once)
+                           'traffic': traffic, 'traffic_source': prov,
+                           'algorithmic_bytes_per_launch': int(by / cnt), 'splitk_overhead_bytes_per_launch': int(over / cnt),
+                           'avg_launch_us': round(tt / cnt * 1e6, 2), 'tflops': round(fl / tt / 1e12, 2),
+                           'mfma_frac': round(fl / tt / peak, 5), 'priced_max_hbm_mfma_frac': round(troof / tt, 5),
                            'launches_per_step': cnt, 'gemm_launches_per_step': launches,
                            'gemm_time_ms_per_step': round(tot_t * 1e3, 3),
                            'all_gemm_tflops': round(sum(x[0] for x in agg.values()) / tot_t / 1e12, 2),
-                           'all_gemm_roofline_frac': round(sum(x[4] for x in agg.values()) / tot_t, 5)}
+                           'all_gemm_roofline_frac': round(sum(x[4] for x in agg.values()) / tot_t, 5),
+                           'all_gemm_splitk_overhead_gb_per_step': round(sum(x[5] for x in agg.values()) / 1e9, 3)}
+        log('timing every distinct window-attention launch of the step ...')
+        arows = attn_profile(eng, data)
+        res['wmsa'] = wmsa_block(arows, peak)
+        res['wmsa']['note'] = ('counted FLOPs = QK^T + AV only (4*64*64*D per head-window fwd, 2x bwd; SURVEY 8d); mfma_frac = counted / time / '
+                               f'{peak / 1e12:.0f} TFLOP/s; hbm_frac = algorithmic bytes / time / {PEAK_HBM / 1e12:.0f} TB/s')
+        dumpa = os.environ.get('FW_ATTN_DUMP')
+        if dumpa:
+            with open(dumpa, 'w') as f:
+                f.write('kind,pass,dtype,D,nkt,lfs,B,H,W,heads,L,mode,shift,launches_per_step,us_per_launch,counted_TFLOPs,GBs\n')
+                for kind, way, sig, cnt_, fl_, by_, t_ in sorted(arows, key=lambda r: -r[3] * r[6]):
+                    f.write(f'{kind},{way},{sig[1]},{sig[2]},{sig[3]},{sig[4]},{sig[6]},{sig[7]},{sig[8]},{sig[9]},{sig[10]},{sig[11]},{sig[12]},'
+                            f'{cnt_},{t_ * 1e6:.1f},{fl_ / t_ / 1e12:.1f},{by_ / t_ / 1e9:.0f}\n')
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(host_threads())
     if rank == 0:

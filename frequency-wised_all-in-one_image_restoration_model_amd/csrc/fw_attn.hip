@@ -432,11 +432,33 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_kernel(AttnArgs a) {
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) dbacc[kt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int win = blockIdx.x; win < a.nwin; win += gridDim.x) {
+    // A workgroup walks a CONTIGUOUS range of windows: they belong to one image (or a few), so the three coefficient-gradient
+    // sums of (image, head) are carried in registers across windows and leave as ONE atomic triple per wave when the image
+    // changes -- per-window atomics on the B * heads * 3 hot words serialised (same-address atomics), and every one of them
+    // sat in front of the next window's tile loads in the in-order vmcnt queue.
+    const int per = (a.nwin + gridDim.x - 1) / gridDim.x;
+    const int win_begin = blockIdx.x * per, win_end = min(a.nwin, win_begin + per);
+    float cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
+    int cs_b = -1;
+    auto flush_coef = [&]() {
+        if constexpr (LFS >= 1) {
+            if (cs_b >= 0) {
+                const float t1 = wave_sum(cs1), t2 = wave_sum(cs2), t3 = wave_sum(cs3);
+                if (l == 0) {
+                    float* dc = a.dcoef + ((size_t)cs_b * a.heads + h) * 3;
+                    atomicAdd(dc, t1); atomicAdd(dc + 1, t2);
+                    if (LFS == 2) atomicAdd(dc + 2, t3);
+                }
+            }
+            cs1 = cs2 = cs3 = 0.f;
+        }
+    };
+    for (int win = win_begin; win < win_end; ++win) {
         const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
         const bool last_y = wy == nWy - 1, last_x = wx == nWx - 1;
         const int nq = lq * a.B + b;
         const size_t item = ((size_t)win * a.L + lq) * a.heads + h;
+        if (b != cs_b) { flush_coef(); cs_b = b; }
         TileLoad<T, D> tq, tdo;
         tq.issue(a.q, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
         tdo.issue(a.dout, a.lddo, nq, wy, wx, a.H, a.W, a.shift, h * D);
@@ -560,11 +582,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_kernel(AttnArgs a) {
                             dp[jt][r] = dp[jt][r] * ca;
                         }
                 }
-                s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
-                if (l == 0) {
-                    float* dc = a.dcoef + ((size_t)b * a.heads + h) * 3;
-                    atomicAdd(dc, s1); atomicAdd(dc + 1, s2); atomicAdd(dc + 2, s3);
-                }
+                cs1 += s1; cs2 += s2; cs3 += s3;
             }
             // D_i (NKT == 1: straight from registers), dS^T = P^T o (dP^T - D_i)
             if constexpr (NKT == 1) {
@@ -611,6 +629,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_kernel(AttnArgs a) {
         store_rows16<T, D>(sY, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
         // the next window's Q / dO loads touch neither sY nor anything a wave still reads
     }
+    flush_coef();
     // flush the bias-gradient accumulators: fold the (i, j) pairs into the 225 relative positions on chip, then one
     // atomic per bin into the parameter layout [table][225][heads] (all workgroups of a head hit the same 225 words)
     float* bins = reinterpret_cast<float*>(smem + S::OFF_BIN);
@@ -637,12 +656,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_kernel(AttnArgs a) {
 template <typename T, int D, int NKT, int LFS>
 int fwd_launch(const AttnArgs& a, hipStream_t st) {
     using S = Smem<T, D, NKT, LFS>;
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, D, NKT, LFS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, S::FWD_BYTES);
-        done = true;
-    }
+    FW_SET_LDS_ONCE((attn_fwd_kernel<T, D, NKT, LFS>), S::FWD_BYTES);
     const int items = a.nwin * a.L * a.heads;
     hipLaunchKernelGGL((attn_fwd_kernel<T, D, NKT, LFS>), dim3(items < 4096 ? items : 4096), dim3(NTH), S::FWD_BYTES, st, a);
     FW_LAUNCH_RET();
@@ -650,12 +664,7 @@ int fwd_launch(const AttnArgs& a, hipStream_t st) {
 template <typename T, int D, int NKT, int LFS>
 int bwd_launch(const AttnArgs& a, hipStream_t st) {
     using S = SmemB<T, D, NKT, LFS>;
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<T, D, NKT, LFS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, S::BYTES);
-        done = true;
-    }
+    FW_SET_LDS_ONCE((attn_bwd_kernel<T, D, NKT, LFS>), S::BYTES);
     hipLaunchKernelGGL((attn_bwd_kernel<T, D, NKT, LFS>), dim3(a.chunks, a.heads, a.L), dim3(NTH), S::BYTES, st, a);
     FW_LAUNCH_RET();
 }

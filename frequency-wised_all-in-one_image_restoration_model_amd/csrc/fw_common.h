@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 #define FW_DT_F32 0
 #define FW_DT_BF16 1
@@ -197,6 +198,16 @@ template <int MT, int NT> FW_DEV void zero_acc(f32x4 (&acc)[MT][NT]) {
     do {                                                                                     \
         hipError_t e__ = hipGetLastError();                                                  \
         return e__ == hipSuccess ? 0 : (int)e__;                                             \
+    } while (0)
+
+// Raise a kernel's dynamic-LDS limit exactly once per template instantiation.  Entry points are called from the Python main
+// thread AND from autograd worker threads: an unsynchronised `static bool` raced there.
+#define FW_SET_LDS_ONCE(kern, bytes)                                                         \
+    do {                                                                                     \
+        static std::once_flag once__;                                                        \
+        std::call_once(once__, [&] {                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+        });                                                                                  \
     } while (0)
 
 static inline int fw_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -888,8 +888,7 @@ template <typename T, int MODE>
 static int dwconv_tile_launch(const T* in, long ldi, const float* w, const float* bias, const T* pre, T* out, T* out2, long ldo, int B, int H, int W,
                               int C, hipStream_t st) {
     const size_t lds = (size_t)(DT_TY + 2) * ((DT_TX + 2) * DT_CB * sizeof(T) + 128);
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_tile_kernel<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    FW_SET_LDS_ONCE((dwconv_tile_kernel<T, MODE>), lds);
     long nb = (long)B * (H / DT_TY) * ((W + DT_TX - 1) / DT_TX) * ((C + DT_CB - 1) / DT_CB);
     nb = (nb + 7) / 8 * 8;
     hipLaunchKernelGGL((dwconv_tile_kernel<T, MODE>), dim3((unsigned)nb), dim3(256), lds, st, in, ldi, w, bias, pre, out, out2, ldo, B, H, W, C);

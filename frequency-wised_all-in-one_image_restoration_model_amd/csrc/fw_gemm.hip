@@ -549,14 +549,292 @@ __global__ __launch_bounds__(256) void gemm_tr_kernel(GemmArgs a) {
     }
 }
 
+// ---- the same product with a DEEP global -> LDS pipeline ------------------------------------------------------------
+// gemm_tr_kernel above keeps ONE stage in flight per workgroup and drains it (`__syncthreads()` = vmcnt(0)) every K step: with
+// two workgroups per CU a step costs one L2 / fabric round trip (1.4 us for 32 KB measured in the B = 16 step), i.e. the kernel
+// is bound by LATENCY, not by bytes or MFMAs.  Here the stages form a ring of NS LDS buffers: NS-1 stages are in flight, a wave
+// waits only for ITS loads of the oldest one (counted `s_waitcnt vmcnt(N)`: loads complete in issue order), a raw `s_barrier`
+// then makes every wave's share of that stage visible, the buffer freed by the previous step is re-issued at once, and the
+// MFMAs of the stage run while the younger stages keep arriving.  One barrier per stage; WAR is covered by the same barrier
+// (a wave reaches it only after the MFMAs that consumed its fragments of the previous stage).
+// hipcc (ROCm 7.2) cannot tell which LDS bytes an in-flight global_load_lds will write, so it puts `s_waitcnt vmcnt(0)` in front
+// of the first ds_read that follows one (it does so in gemm_tr_kernel / gemm_kernel above: their "prefetch" of the next stage is
+// waited for BEFORE the current stage is computed -- no overlap inside a workgroup).  The ring therefore issues its LDS-DMA from
+// inline asm, which the compiler neither counts nor waits for, and counts completion itself (cdna_hip_programming.md 5.7):
+// M0 carries the wave-uniform LDS destination and is written in the same statement that uses it.
+template <int N> FW_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+FW_DEV void glds16_asm(const char* gsrc, char* lds_dst) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+// one [KT tokens][128 cols] tile of a token-major operand; a wave-instruction fills 4 token rows (1 KB, lane-linear)
+template <int KT>
+FW_DEV void glds_issue_km_t(const char* base, long ld, int col0, int cols_total, int k0, char* tile) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int it = 0; it < KT / 16; ++it) {
+        const int R0 = wave * (KT / 4) + it * 4;
+        const int r = R0 + (lane >> 4), p = lane & 15;
+        int col = col0 + ((p ^ swz256(r)) << 3);
+        if (col >= cols_total) col = 0;
+        const char* g = base + ((long)(k0 + r) * ld + col) * 2;
+        glds16_asm(g, tile + R0 * 256);
+    }
+}
+// the k-contiguous image of gemm_kernel ([ROWS][128 B], slot swizzle on the source address), asm-issued
+template <typename T, int ROWS>
+FW_DEV void glds_issue_asm(const char* base, long ld, int row0, int rows_total, int kbyte0, char* tile) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int it = 0; it < ROWS / 32; ++it) {
+        const int R0 = (wave * (ROWS / 32) + it) * 8;
+        const int r = R0 + (lane >> 3), p = lane & 7;
+        int gr = row0 + r;
+        if (gr >= rows_total) gr = rows_total - 1;
+        glds16_asm(base + (long)gr * ld * TT<T>::SZ + kbyte0 + ((p ^ (swz(r) >> 4)) << 4), tile + R0 * LDS_ROW);
+    }
+}
+
+template <bool XT, int KT, int NS>
+__global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
+    using T = bf16raw;
+    static_assert(XT || KT == 64, "the k-contiguous X image is built for 64-deep steps");
+    static_assert(NS >= 3 && NS <= 5, "ring depth");
+    constexpr int WM = 4;
+    constexpr int XB = XT ? KT * 256 : 128 * LDS_ROW, WB = KT * 256, STAGE = XB + WB;
+    constexpr int LPS = (XT ? KT / 16 : 4) + KT / 16;          // global_load_lds instructions per thread and stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto xs = [&](int i) -> char* { return smem + i * STAGE; };
+    auto ws = [&](int i) -> char* { return smem + i * STAGE + XB; };
+    const int wave = threadIdx.x >> 6;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {                                                     // contiguous eighths of the (slice, n tile, m tile) order per XCD, see gemm_kernel
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        if (gridDim.z > 1 && (total & 7) == 0) {
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            bx = (int)(w % gridDim.x);
+            by = (int)((w / gridDim.x) % gridDim.y);
+            bz = (int)(w / (gridDim.x * gridDim.y));
+        } else if (gridDim.z == 1 && gridDim.y > 1 && (total & 7) == 0) {
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            const unsigned per_band = 8 * gridDim.y;
+            const unsigned band = w / per_band, first = band * 8;
+            const unsigned gsz = min(gridDim.x - first, 8u);
+            bx = (int)(first + (w % per_band) % gsz);
+            by = (int)((w % per_band) / gsz);
+        }
+    }
+    const int m_blk = bx * 128, n_blk = by * 128;
+    const int wm0 = (wave & 1) * 64, wn0 = (wave >> 1) * 64;
+    const int k_begin = bz * a.kper;
+    const int k_end = min(a.K, k_begin + a.kper);
+    const int nsteps = (k_end - k_begin) / KT;           // whole steps only (host guarantees K % 64 == 0)
+
+    f32x4 acc[4][WM], xsacc[WM];
+    zero_acc(acc);
+#pragma unroll
+    for (int m = 0; m < WM; ++m) xsacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_xsum = XT && a.xsum != nullptr && by == 0 && wn0 == 0;    // wave-uniform
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // bf16 1.0 x 8
+
+    auto issue = [&](int step, int buf) {
+        const int k0 = k_begin + step * KT;
+        if constexpr (XT) glds_issue_km_t<KT>(a.X, a.ldx, m_blk, a.M, k0, xs(buf));
+        else glds_issue_asm<T, BM>(a.X, a.ldx, m_blk, a.M, k0 * 2, xs(buf));
+        glds_issue_km_t<KT>(a.W, a.ldw, n_blk, a.N, k0, ws(buf));
+    };
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nsteps) issue(p, p);
+    int buf = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // stages s+1 .. s+NS-2 may stay in flight; near the tail fewer were issued
+        const int younger = min(NS - 2, nsteps - 1 - s);
+        if (younger >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
+        else if (NS >= 4 && younger == NS - 3) wait_vmcnt<(NS - 3) * LPS>();
+        else if (NS >= 5 && younger == NS - 4) wait_vmcnt<(NS >= 5 ? NS - 4 : 0) * LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NS - 1 < nsteps) issue(s + NS - 1, buf == 0 ? NS - 1 : buf - 1);   // the buffer step s-1 has just released
+#pragma unroll
+        for (int c = 0; c < KT / 32; ++c) {
+            uint4 af[4], bfr[WM];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = frag_tr256(ws(buf), wn0 + 16 * m, c);
+#pragma unroll
+            for (int n = 0; n < WM; ++n) bfr[n] = XT ? frag_tr256(xs(buf), wm0 + 16 * n, c) : frag_sw(xs(buf), wm0 + 16 * n, c);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < WM; ++n) mma_chunk<T>(acc[m][n], af[m], bfr[n]);
+            if (do_xsum) {
+#pragma unroll
+                for (int n = 0; n < WM; ++n) mma_chunk<T>(xsacc[n], ones, bfr[n]);
+            }
+        }
+        buf = buf + 1 == NS ? 0 : buf + 1;
+    }
+    const int l = lane_id();
+    if (do_xsum && (l >> 4) == 0) {                      // every row of the ones-product holds the column sums: take row 0
+#pragma unroll
+        for (int n = 0; n < WM; ++n) {
+            const int m = m_blk + wm0 + n * 16 + l;
+            if (m < a.M) {
+                if (a.xsum_zstride > 0) a.xsum[(long)bz * a.xsum_zstride + m] = xsacc[n][0];
+                else atomicAdd(a.xsum + m, xsacc[n][0]);
+            }
+        }
+    }
+    f32x4 bias4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+        bias4[nt] = epi_bias(a, n0 < a.N ? n0 : 0, bz);
+    }
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        const int m = m_blk + wm0 + mt * 16 + (l & 15);
+        const int mc = m < a.M ? m : a.M - 1;
+        const float rs = a.rowscale ? a.rowscale[mc / a.rows_per_scale] : 1.0f;
+        uint4 ext[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+            epi_fetch<T>(a, ext[nt], mc, n0 < a.N ? n0 : 0, bz);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+            if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], ext[nt], acc[nt][mt], m, n0, rs, bz);
+        }
+    }
+}
+
+template <bool XT, int KT, int NS>
+int launch_tr_ring(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)NS * ((XT ? KT * 256 : 128 * LDS_ROW) + KT * 256);
+    FW_SET_LDS_ONCE((gemm_tr_ring_kernel<XT, KT, NS>), lds);
+    hipLaunchKernelGGL((gemm_tr_ring_kernel<XT, KT, NS>), dim3(fw_cdiv(a.M, 128), fw_cdiv(a.N, 128), a.splitk), dim3(256), lds, st, a);
+    FW_LAUNCH_RET();
+}
+
+// ---- gemm_kernel's NT product (both operands k-contiguous, whole 128-byte K steps) on the same ring ---------------------
+// Forward Linears of the C >= 224 stages, im2col / pixel-shuffle convolutions: y = x W^T.  Stage = [128 + BN rows][128 B].
+// BN = 128: 4 stages of 32 KB (1 workgroup per CU, 96 KB in flight); BN = 64: 3 stages of 24 KB (2 workgroups per CU).
+template <typename T, int BN, int NS>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a) {
+    constexpr int KT = 128 / TT<T>::SZ;
+    constexpr int WM = (BN == 128) ? 4 : 2;
+    constexpr int XBYTES = BM * LDS_ROW, WBYTES = BN * LDS_ROW, STAGE = XBYTES + WBYTES;
+    constexpr int LPS = BM / 32 + BN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto xs = [&](int i) -> char* { return smem + i * STAGE; };
+    auto ws = [&](int i) -> char* { return smem + i * STAGE + XBYTES; };
+    const int wave = threadIdx.x >> 6;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        if (gridDim.z > 1 && (total & 7) == 0) {
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            bx = (int)(w % gridDim.x);
+            by = (int)((w / gridDim.x) % gridDim.y);
+            bz = (int)(w / (gridDim.x * gridDim.y));
+        } else if (gridDim.z == 1 && gridDim.y > 1 && (total & 7) == 0) {
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            const unsigned per_band = 8 * gridDim.y;
+            const unsigned band = w / per_band, first = band * 8;
+            const unsigned gsz = min(gridDim.x - first, 8u);
+            bx = (int)(first + (w % per_band) % gsz);
+            by = (int)((w % per_band) / gsz);
+        }
+    }
+    const int m_blk = bx * BM, n_blk = by * BN;
+    const int wm0 = (BN == 128) ? (wave & 1) * 64 : wave * 32;
+    const int wn0 = (BN == 128) ? (wave >> 1) * 64 : 0;
+    const int k_begin = bz * a.kper;
+    const int k_end = min(a.K, k_begin + a.kper);
+    const int nsteps = (k_end - k_begin) / KT;           // whole steps (host: K % KT == 0)
+
+    f32x4 acc[4][WM];
+    zero_acc(acc);
+    auto issue = [&](int step, int buf) {
+        const int kb = (k_begin + step * KT) * TT<T>::SZ;
+        glds_issue_asm<T, BM>(a.X, a.ldx, m_blk, a.M, kb, xs(buf));
+        glds_issue_asm<T, BN>(a.W, a.ldw, n_blk, a.N, kb, ws(buf));
+    };
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nsteps) issue(p, p);
+    int buf = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const int younger = min(NS - 2, nsteps - 1 - s);
+        if (younger >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
+        else if (NS >= 4 && younger == NS - 3) wait_vmcnt<(NS >= 4 ? NS - 3 : 0) * LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NS - 1 < nsteps) issue(s + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint4 af[4], bfr[WM];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = frag_sw(ws(buf), wn0 + 16 * m, c);
+#pragma unroll
+            for (int n = 0; n < WM; ++n) bfr[n] = frag_sw(xs(buf), wm0 + 16 * n, c);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < WM; ++n) mma_chunk<T>(acc[m][n], af[m], bfr[n]);
+        }
+        buf = buf + 1 == NS ? 0 : buf + 1;
+    }
+    const int l = lane_id();
+    f32x4 bias4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+        bias4[nt] = epi_bias(a, n0 < a.N ? n0 : 0, bz);
+    }
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        const int m = m_blk + wm0 + mt * 16 + (l & 15);
+        const int mc = m < a.M ? m : a.M - 1;
+        const float rs = a.rowscale ? a.rowscale[mc / a.rows_per_scale] : 1.0f;
+        uint4 ext[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+            epi_fetch<T>(a, ext[nt], mc, n0 < a.N ? n0 : 0, bz);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+            if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], ext[nt], acc[nt][mt], m, n0, rs, bz);
+        }
+    }
+}
+
+template <typename T, int BN, int NS>
+int launch_ring(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)NS * (BM + BN) * LDS_ROW;
+    FW_SET_LDS_ONCE((gemm_ring_kernel<T, BN, NS>), lds);
+    dim3 grid(fw_cdiv(a.M, BM), fw_cdiv(a.N, BN), a.splitk);
+    hipLaunchKernelGGL((gemm_ring_kernel<T, BN, NS>), grid, dim3(256), lds, st, a);
+    FW_LAUNCH_RET();
+}
+
 template <bool XT>
 int launch_tr(const GemmArgs& a, hipStream_t st) {
     const size_t lds = 4 * 64 * 256;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tr_kernel<XT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    FW_SET_LDS_ONCE(gemm_tr_kernel<XT>, lds);
     hipLaunchKernelGGL(gemm_tr_kernel<XT>, dim3(fw_cdiv(a.M, 128), fw_cdiv(a.N, 128), a.splitk), dim3(256), lds, st, a);
     FW_LAUNCH_RET();
 }
@@ -732,11 +1010,7 @@ int launch_stream(const GemmArgs& a, hipStream_t st) {
     const int ny = fw_cdiv(a.N, maxb);
     const int bnp = fw_cdiv(fw_cdiv(a.N, ny), 64) * 64;
     const size_t lds = (size_t)bnp * RL + (size_t)bnp * 4;       // W panel + bias of its columns
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<T, NCH, WT, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize, 66 * 1024);
-        attr_done = true;
-    }
+    FW_SET_LDS_ONCE((gemm_stream_kernel<T, NCH, WT, EXT>), 66 * 1024);
     const int strips = fw_cdiv(a.M, 32);
     int gx = fw_cdiv(strips, 8);
     const int cap = 512 / ny > 0 ? 512 / ny : 1;                    // 256 CUs x 2 workgroups
@@ -762,12 +1036,7 @@ int dispatch_stream(const GemmArgs& a, int wt, hipStream_t st) {
 template <typename T, int BN, bool XT, bool WT, bool GX, bool GW>
 int launch(const GemmArgs& a, hipStream_t st) {
     const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, BN, XT, WT, GX, GW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    FW_SET_LDS_ONCE((gemm_kernel<T, BN, XT, WT, GX, GW>), lds);
     dim3 grid(fw_cdiv(a.M, BM), fw_cdiv(a.N, BN), a.splitk);
     hipLaunchKernelGGL((gemm_kernel<T, BN, XT, WT, GX, GW>), grid, dim3(256), lds, st, a);
     FW_LAUNCH_RET();
@@ -780,6 +1049,8 @@ int dispatch_trans(const GemmArgs& a, int xt, int wt, hipStream_t st) {
     const bool whole = a.K % kt == 0;
     const bool gx = !xt && whole && a.x_op == 0, gw = !wt && whole && a.w_op == 0;
     if (!xt && !wt) {
+        static const int ring = getenv("FW_GEMM_RING") ? atoi(getenv("FW_GEMM_RING")) : 1;        // 0: gemm_kernel (one stage in flight)
+        if (gx && gw && ring && a.kper % kt == 0) return BN == 128 ? launch_ring<T, BN, 4>(a, st) : launch_ring<T, BN, 3>(a, st);
         if (gx && gw) return launch<T, BN, false, false, true, true>(a, st);
         if (gx) return launch<T, BN, false, false, true, false>(a, st);
         if (gw) return launch<T, BN, false, false, false, true>(a, st);
@@ -848,10 +1119,20 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
     // 64-deep K steps: W (and X) tiles go to LDS as they are and are read with transposing LDS reads (gemm_tr_kernel)
     static const int use_tr = getenv("FW_GEMM_TR") ? atoi(getenv("FW_GEMM_TR")) : 3;
     if (dtype == FW_DT_BF16 && w_trans && x_op == 0 && w_op == 0 && N > 64 && K % 64 == 0 && a.kper % 64 == 0 && ldw % 8 == 0) {
-        if (x_trans && (use_tr & 1) && ldx % 8 == 0) { g_last_variant = 100011; return launch_tr<true>(a, st); }
+        static const int ring = getenv("FW_GEMM_TR_RING") ? atoi(getenv("FW_GEMM_TR_RING")) : 1;     // 0: one stage in flight (gemm_tr_kernel)
+        if (x_trans && (use_tr & 1) && ldx % 8 == 0) {
+            g_last_variant = 100011;
+            if (ring == 1) return launch_tr_ring<true, 32, 4>(a, st);
+            if (ring == 2) return launch_tr_ring<true, 64, 3>(a, st);
+            if (ring == 3) return launch_tr_ring<true, 64, 4>(a, st);
+            if (ring == 4) return launch_tr_ring<true, 32, 5>(a, st);
+            return launch_tr<true>(a, st);
+        }
         static const long tr_min_tiles = getenv("FW_GEMM_TR_MIN_TILES") ? atol(getenv("FW_GEMM_TR_MIN_TILES")) : 384;
         if (!x_trans && (use_tr & 2) && !xsum && (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk >= tr_min_tiles) {
             g_last_variant = 100001;
+            if (ring == 2 || ring == 1) return launch_tr_ring<false, 64, 3>(a, st);
+            if (ring == 3 || ring == 4) return launch_tr_ring<false, 64, 4>(a, st);
             return launch_tr<false>(a, st);
         }
     }

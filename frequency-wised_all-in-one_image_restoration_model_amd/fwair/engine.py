@@ -229,6 +229,11 @@ class TrainEngine:
         assert dev.type == 'cuda', 'TrainEngine needs the HIP device'
         self.flat_p = flatten_parameters(self.trainable, dev)
         self.flat_k = flatten_parameters(enc_k, dev)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            # identical replicas at start -- BEFORE the bf16 operand shadows are cast below, so that no rank's first
+            # forward runs on the shadow of its own random initialisation
+            dist.broadcast(self.flat_p, src=0)
+            dist.broadcast(self.flat_k, src=0)
         self.n_enc = _layout(enc_q)[1]                       # padded extents: the two encoder buffers share one layout
         self.n = self.flat_p.numel()
         assert self.flat_k.numel() == self.n_enc
@@ -256,9 +261,6 @@ class TrainEngine:
         self._fuse_tables(net)
         moco._ema_hook = self._ema
         self.allreduce = GradAllReducer(self.flat_g, wire_dtype=grad_wire_dtype)
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.broadcast(self.flat_p, src=0)             # identical replicas at start
-            dist.broadcast(self.flat_k, src=0)
         Fn.config.shadow_epoch += 1
         Fn.config.direct_grads = True                     # kernels add into the flat .grad views; autograd sees None
         self._graph = None
@@ -505,16 +507,26 @@ class TrainEngine:
         single = self.allreduce.world == 1
         self._gsplit = None
         if self.split_backward or not single:
+            ok = 1
             try:
                 self._capture_split(warmup)
+            except RuntimeError as e:                        # HIP / capture errors only: never lose the run to the overlap
+                import warnings
+                warnings.warn(f'fwair: two-stage backward capture failed ({type(e).__name__}: {e}); all-reduce will follow the backward pass')
+                ok = 0
+                self._split = None
+                torch.cuda.synchronize()
+            if not single:
+                # the fallback issues ONE whole-buffer all-reduce per step, the split scheme two partial ones: every rank must take
+                # the same path or the collectives mismatch and the job hangs -- agree on the minimum of the success flags
+                flag = torch.tensor([ok], dtype=torch.int32, device=self.flat_p.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if ok:
                 self._restore(snap)
                 self._graph = True
                 return
-            except Exception as e:                           # never lose the run to the overlap: fall back to reduce-after-backward
-                import warnings
-                warnings.warn(f'fwair: two-stage backward capture failed ({type(e).__name__}: {e}); all-reduce will follow the backward pass')
-                self._gsplit, self._split = None, None
-                torch.cuda.synchronize()
+            self._gsplit = None
         ops.reserve_capture_tables()
         self._g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g1):

@@ -8,7 +8,11 @@ import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, 'libfwair_hip.so')
-HEADER_PATH = os.path.join(os.path.dirname(_PKG), 'include', 'fwair.h')
+# the header ships inside the package (build.sh copies include/fwair.h next to this file); a source checkout that has not been
+# built yet falls back to the repository's include/ directory
+HEADER_PATH = next((p for p in (os.path.join(os.path.dirname(os.path.abspath(__file__)), 'fwair.h'),
+                                os.path.join(os.path.dirname(_PKG), 'include', 'fwair.h')) if os.path.exists(p)),
+                   os.path.join(os.path.dirname(_PKG), 'include', 'fwair.h'))
 
 F32, BF16 = 0, 1
 _CT = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float}

@@ -183,7 +183,7 @@ class DecLeWinTransformerBlock(nn.Module):
     """decoder_Uformer.py:504-756 (`LeWinTransformerBlock`, plain + all_* path)."""
 
     def __init__(self, dim, input_resolution, num_heads, win_size=8, shift_size=0, mlp_ratio=4., drop_path=0.,
-                 all_degradation_embedding_method=()):
+                 all_degradation_embedding_method=(), debug_mode=False):
         super().__init__()
         self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
         self.win_size, self.shift_size = win_size, shift_size
@@ -192,6 +192,10 @@ class DecLeWinTransformerBlock(nn.Module):
             self.win_size = min(input_resolution)
         if self.win_size != WIN:
             raise NotImplementedError('feature maps smaller than one 8x8 window')
+        self.debug_mode = bool(debug_mode)
+        if self.debug_mode:                                                     # :518-519 (no parameters, no buffers: same state_dict)
+            from net.utils.frequency_decompose import FrequencyDecompose
+            self.visual_decompose = FrequencyDecompose('frequency_decompose', 1, input_resolution[0], input_resolution[1], inverse='visual')
         self.norm1 = nn.LayerNorm(dim)
         self.attn = DecWindowAttention(input_resolution, dim, (self.win_size, self.win_size), num_heads,
                                        all_degradation_embedding_method)
@@ -200,26 +204,44 @@ class DecLeWinTransformerBlock(nn.Module):
         self.mlp = LeFF(dim, int(dim * mlp_ratio))
         self._name = ''
 
-    def run(self, x, batch, coef):
+    def _spectrum(self, t, batch, h):
+        """decoder_Uformer.py:668-673 / :731-736: magnitude spectrum (HIP DFT, `visual` mode) of a token-major activation as a
+        [B, C, H, W] map, averaged over batch and channels -> [H, W]."""
+        img = t.detach().float().reshape(batch, h, h, t.shape[1]).permute(0, 3, 1, 2).contiguous()
+        return self.visual_decompose(img).squeeze(0).mean(0).mean(0)
+
+    def run(self, x, batch, coef, visual=None):
+        """visual: list that receives this block's debug payload [spectrum_before, spectrum_after, embed_lamb] (:753-754)."""
         rows, C = x.shape
         h = _tokens_hw(rows, batch)
-        dp = Fn.droppath_scale(self._name, batch, self.drop_path_rate, self.training, x.device)
+        # two independent masks per block, as the reference's two self.drop_path(...) calls draw (decoder_Uformer.py:739,751)
+        dp = Fn.droppath_scale(self._name + 'attn', batch, self.drop_path_rate, self.training, x.device)
+        dp2 = Fn.droppath_scale(self._name + 'mlp', batch, self.drop_path_rate, self.training, x.device)
         x, xn = Fn.LnResFn.apply(x, self.norm1.weight, self.norm1.bias)
         qkv = self.attn.qkv(xn)
         geo = (C, batch, h, h, self.num_heads, 1, 0, self.shift_size, self.attn.lfs_mode if coef is not None else 0)
         tab = self.attn.relative_position_bias_table
         o = Fn.WindowAttnFn.apply(qkv, tab.unsqueeze(0), coef, geo, tab, getattr(coef, '_fw_dgrad', None))
-        x = Fn.linear(o, self.attn.proj.weight, self.attn.proj.bias, residual=x, rowscale=dp, rows_per_scale=h * h)
+        if visual is not None:
+            # the attention branch is needed on its own (before the residual add): plain projection, then the add
+            y = Fn.linear(o, self.attn.proj.weight, self.attn.proj.bias, out_f32=True)
+            lamb = []
+            if coef is not None:           # (a, b, c) = (1 + lambda_last, -lambda_last / 64, ...): the LAST band's lambda, [B, 1, heads] (:277-296)
+                lamb = (coef.detach()[:, :, 0] - 1.0).reshape(batch, 1, self.num_heads)
+            visual.append([self._spectrum(xn, batch, h), self._spectrum(y, batch, h), lamb])
+            x = x + (y if dp is None else y * dp.repeat_interleave(h * h)[:, None])
+        else:
+            x = Fn.linear(o, self.attn.proj.weight, self.attn.proj.bias, residual=x, rowscale=dp, rows_per_scale=h * h)
         x, xn2 = Fn.LnResFn.apply(x, self.norm2.weight, self.norm2.bias)
-        return self.mlp.run(xn2, x, dp, batch)
+        return self.mlp.run(xn2, x, dp2, batch)
 
 
 class DecBasicUformerLayer(nn.Module):
-    def __init__(self, dim, input_resolution, depth, num_heads, win_size, mlp_ratio, drop_path, methods):
+    def __init__(self, dim, input_resolution, depth, num_heads, win_size, mlp_ratio, drop_path, methods, debug_mode=False):
         super().__init__()
         self.blocks = nn.ModuleList([
             DecLeWinTransformerBlock(dim, input_resolution, num_heads, win_size, 0 if i % 2 == 0 else win_size // 2, mlp_ratio,
-                                     drop_path[i] if isinstance(drop_path, list) else drop_path, methods)
+                                     drop_path[i] if isinstance(drop_path, list) else drop_path, methods, debug_mode)
             for i in range(depth)])
 
 
@@ -243,8 +265,7 @@ class UformerDecoder(nn.Module):
         super().__init__()
         self.opt = opt
         img_size = _resolve_img_size(opt, img_size)
-        if getattr(opt, 'debug_mode', False):
-            raise NotImplementedError('debug_mode spectra are not produced by the HIP path')
+        self.debug_mode = bool(getattr(opt, 'debug_mode', False))               # :847 -- forward then returns (restored, visual_freqs)
         for m in opt.degradation_embedding_method:
             if 'all' not in m and m not in ('None', 'none'):
                 raise NotImplementedError(f'degradation_embedding_method={m!r} does not run in the reference either '
@@ -258,7 +279,7 @@ class UformerDecoder(nn.Module):
         dec_dpr = enc_dpr[::-1]
         self.input_proj = InputProj(in_chans, E)
         self.output_proj = OutputProj(2 * E, out_chans)
-        mk = lambda dim, res, d, h, dpr: DecBasicUformerLayer(dim, (res, res), d, h, win_size, mlp_ratio, dpr, methods)
+        mk = lambda dim, res, d, h, dpr: DecBasicUformerLayer(dim, (res, res), d, h, win_size, mlp_ratio, dpr, methods, self.debug_mode)
         o = 0
         for i in range(4):
             setattr(self, f'encoderlayer_{i}', mk(E * 2 ** i, img_size // 2 ** i, depths[i], num_heads[i], enc_dpr[o:o + depths[i]]))
@@ -332,9 +353,15 @@ class UformerDecoder(nn.Module):
         x = x.contiguous().float()
         y = self.input_proj.run(x)
 
+        visual_freqs = [] if self.debug_mode else None                          # :1130, one list per layer in forward order
+
         def layer(name, t):
+            vis = None
+            if visual_freqs is not None:
+                vis = []
+                visual_freqs.append(vis)
             for blk in getattr(self, name).blocks:
-                t = blk.run(t, B, next(coefs))
+                t = blk.run(t, B, next(coefs), vis)
             return t
 
         conv = []
@@ -347,7 +374,10 @@ class UformerDecoder(nn.Module):
         for i in reversed(range(4)):
             y = getattr(self, f'upsample_{i}').run_cat(y, conv[i], B)
             y = layer(f'decoderlayer_{i}', y)
-        return self.output_proj.run(y, x)
+        out = self.output_proj.run(y, x)
+        if self.debug_mode:                                                     # :1168-1169
+            return out, visual_freqs
+        return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -436,7 +466,9 @@ class EncLeWinTransformerBlock(nn.Module):
         """x: f32 [(l b) H W, C];  nimg = L*B images."""
         rows, C = x.shape
         h = _tokens_hw(rows, nimg)
-        dp = Fn.droppath_scale(self._name, nimg, self.drop_path_rate, self.training, x.device)
+        # two independent masks per block (encoder_Uformer.py:679-680)
+        dp = Fn.droppath_scale(self._name + 'attn', nimg, self.drop_path_rate, self.training, x.device)
+        dp2 = Fn.droppath_scale(self._name + 'mlp', nimg, self.drop_path_rate, self.training, x.device)
         x, xn = Fn.LnResFn.apply(x, self.norm1.weight, self.norm1.bias)
         if self.encoder_msa_type == 'origin':
             geo = (C, nimg, h, h, self.num_heads, 1, 0, self.shift_size, 0)
@@ -451,7 +483,7 @@ class EncLeWinTransformerBlock(nn.Module):
             o = Fn.WindowAttnFn.apply(a.qkv(y1), a.tables(), None, (C, B, h, h, self.num_heads, self.L, 1, self.shift_size, 0), a.table_grads(), None)
             x = Fn.linear(o, a.proj.weight, a.proj.bias, residual=x, rowscale=dp, rows_per_scale=h * h)
         x, xn2 = Fn.LnResFn.apply(x, self.norm2.weight, self.norm2.bias)
-        return self.mlp.run(xn2, x, dp, nimg)
+        return self.mlp.run(xn2, x, dp2, nimg)
 
 
 class EncBasicUformerLayer(nn.Module):

@@ -26,6 +26,7 @@ _own.add_argument('--synthetic_steps', type=int, default=0, help='train on this 
 _own.add_argument('--resume', type=str, default='', help='checkpoint epoch_<E>.pth to continue from (its .opt.pth beside it)')
 _own.add_argument('--save_every', type=int, default=0, help='also checkpoint every this many epochs')
 _own.add_argument('--no_graph', action='store_true', help='eager launches instead of HIP-graph replay')
+_own.add_argument('--no_eval', action='store_true', help='skip the per-epoch evaluation / results.log of train.py:131-139')
 _ARGS, _rest = _own.parse_known_args()
 sys.argv = [sys.argv[0]] + _rest                       # option.py parses sys.argv at import (reference option.py:3)
 
@@ -49,6 +50,9 @@ def sigma_of(task):
     return int(task.split('_')[1]) if task.startswith('denoising_') and task.split('_')[1].isdigit() else 25
 
 
+_LOADER = []                  # (dataset, sampler, loader): built once -- a DataLoader with `num_workers` processes per epoch is a fork storm
+
+
 def batches(epoch, rank, world, B, dev):
     if _ARGS.synthetic_steps > 0:
         sig = [sigma_of(t) for t in opt.de_type] or [25]
@@ -61,14 +65,51 @@ def batches(epoch, rank, world, B, dev):
                 clean, d1, d2 = synth_batch(B, opt.patch_size, sig[i % len(sig)], seed, dev)
             yield d1, d2, clean
         return
-    from torch.utils.data import DataLoader
-    from torch.utils.data.distributed import DistributedSampler
-    from utils.dataset_utils import TrainDataset        # the reference's dataset (needs its root on PYTHONPATH and the data on disk)
-    ds = TrainDataset(opt)
-    sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, drop_last=True)
-    sampler.set_epoch(epoch)
-    for (_, d1, d2, c1, _) in DataLoader(ds, batch_size=B, sampler=sampler, pin_memory=True, drop_last=True, num_workers=opt.num_workers):
+    if not _LOADER:
+        from torch.utils.data import DataLoader
+        from torch.utils.data.distributed import DistributedSampler
+        from utils.dataset_utils import TrainDataset    # the reference's dataset (needs its root on PYTHONPATH and the data on disk)
+        ds = TrainDataset(opt)
+        sampler = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, drop_last=True)
+        _LOADER.append((ds, sampler, DataLoader(ds, batch_size=B, sampler=sampler, pin_memory=True, drop_last=True,
+                                                num_workers=opt.num_workers, persistent_workers=opt.num_workers > 0)))
+    _, sampler, loader = _LOADER[0]
+    sampler.set_epoch(epoch)                             # a new shuffle per epoch, same worker pool
+    for (_, d1, d2, c1, _) in loader:
         yield d1.to(dev, non_blocking=True), d2.to(dev, non_blocking=True), c1.to(dev, non_blocking=True)
+
+
+def evaluate_tasks(net, epoch, dev, results):
+    """train.py:131-139: after every phase-2 epoch, `<E> Epochs Results:` and one `task: PSNR/SSIM` line per test task in results.log.
+    The tiles are restored by fwair.evaluate.tiled_restore (test.py:48-71 on the device, averaging the RESTORED tiles).  With
+    `--synthetic_steps` the test images are synthetic too (4 images of 1.5 x patch_size per task); otherwise the reference's
+    TestDataset is read.  SSIM needs scikit-image, which this package does not depend on: the field is written as nan."""
+    from fwair import augment as A
+    from fwair.evaluate import psnr, tiled_restore
+    results.write('%s Epochs Results:\n' % str(epoch + 1))
+    net.eval()
+    for task in opt.test_de_type:
+        vals = []
+        if _ARGS.synthetic_steps > 0:
+            S = opt.patch_size * 3 // 2
+            clean, _, _ = synth_batch(4, S, 0, 4321, dev)
+            g = torch.Generator(device='cpu'); g.manual_seed(4321)
+            cu8 = (clean * 255.0).round().to(torch.uint8)
+            for i in range(clean.shape[0]):
+                try:
+                    deg = A.degrade(cu8[i], task, g).float().div_(255.0)     # 'denoising_bsd68_25' -> sigma 25; deraining; dehazing
+                except ValueError:
+                    break                                                    # a task without a synthetic stand-in (deblurring)
+                vals.append(psnr(tiled_restore(net, deg[None], opt.crop_test_imgs_size), clean[i:i + 1]))
+        else:
+            from torch.utils.data import DataLoader
+            from utils.dataset_utils import TestDataset
+            for (_, inp, cl) in DataLoader(TestDataset(opt, task), batch_size=1, shuffle=False, num_workers=0):
+                vals.append(psnr(tiled_restore(net, inp.to(dev), opt.crop_test_imgs_size), cl.to(dev)))
+        result = 'PSNR/SSIM: %.2f/%.4f' % (sum(vals) / len(vals) if vals else float('nan'), float('nan'))
+        results.write(task + ': ' + ' ' * (25 - len(task)) + result + '\n')
+    results.flush()
+    net.train()
 
 
 def main():
@@ -103,6 +144,7 @@ def main():
         start = int(st['epoch']) + 1
         eng.set_lr(lr_for_next_epoch(start - 1))
     log = open(opt.output_path + 'train.log', 'a' if _ARGS.resume else 'w') if rank == 0 else None
+    results = open(opt.output_path + 'results.log', 'a' if _ARGS.resume else 'w') if rank == 0 else None      # train.py:36-37
 
     def save(epoch):
         if rank != 0:
@@ -129,9 +171,14 @@ def main():
             log.flush()
         if epoch + 1 == opt.epochs or (_ARGS.save_every and (epoch + 1) % _ARGS.save_every == 0):
             save(epoch)
+        if epoch >= opt.epochs_encoder and rank == 0 and not _ARGS.no_eval:     # train.py:131-139 (rank 0 only: an eval forward has no collective)
+            evaluate_tasks(net, epoch, dev, results)
+        if world > 1:
+            torch.distributed.barrier()
         eng.set_lr(lr_for_next_epoch(epoch))
     if log:
         log.close()
+        results.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

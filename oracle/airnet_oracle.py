@@ -251,8 +251,28 @@ def drop_path_apply(x, dp):
     return x * dp.view(-1, *([1] * (x.ndim - 1))).to(x.dtype)
 
 
-def lewin_block_dec(st, p, x, heads, shift, all_inter, lfs, dp=None):
-    """LeWinTransformerBlock.forward, decoder_Uformer.py:618-756 (plain + all_* path)."""
+def drop_path_pair(dp):
+    """A block calls self.drop_path twice (decoder_Uformer.py:739,751 / encoder_Uformer.py:679-680): timm draws an
+    INDEPENDENT mask for the attention branch and for the MLP branch.  dp: None | (dp_attn, dp_mlp)."""
+    if dp is None:
+        return None, None
+    assert isinstance(dp, (tuple, list)) and len(dp) == 2, 'dp = (attention-branch scale, MLP-branch scale)'
+    return dp
+
+
+def visual_spectrum(tokens, H, W):
+    """decoder_Uformer.py:668-673 / :731-736 (debug_mode): |fftshift(fft2(.))| of the [B, C, H, W] map -- the single band of
+    FrequencyDecompose('frequency_decompose', 1, H, W, inverse='visual') -- averaged over batch and channels -> [H, W].
+    (The reference's fftshift also rolls the batch / channel axes, frequency_decompose.py:32: the means do not see it.)"""
+    B, _, C = tokens.shape
+    img = tokens.view(B, H, W, C).permute(0, 3, 1, 2)
+    spec = torch.fft.fftshift(torch.fft.fft2(img), dim=(-2, -1)).abs()
+    return spec.mean(0).mean(0)
+
+
+def lewin_block_dec(st, p, x, heads, shift, all_inter, lfs, dp=None, debug=None):
+    """LeWinTransformerBlock.forward, decoder_Uformer.py:618-756 (plain + all_* path).
+    debug: a list that receives [spectrum_before, spectrum_after, embed_lamb] (`opt.debug_mode`, :753-754)."""
     B, L, C = x.shape
     H = W = int(math.sqrt(L))
     win = min(WIN, H)
@@ -263,15 +283,20 @@ def lewin_block_dec(st, p, x, heads, shift, all_inter, lfs, dp=None):
     y = F.layer_norm(x, (C,), st[p + 'norm1.weight'], st[p + 'norm1.bias']).view(B, H, W, C)
     if shift > 0:
         y = torch.roll(y, shifts=(-shift, -shift), dims=(1, 2))
+    if debug is not None:
+        before = visual_spectrum(y.reshape(B, H * W, C), H, W)
     yw = window_partition(y, win).view(-1, win * win, C)
     num_win = (H // win) * (W // win)
-    aw = window_attention_lfs(st, p + 'attn.', yw, heads, num_win, all_inter, mask, lfs)
+    aw, _, lambs = window_attention_lfs(st, p + 'attn.', yw, heads, num_win, all_inter, mask, lfs, want_attn=True)
     y = window_reverse(aw.view(-1, win, win, C), win, H, W)
     if shift > 0:
         y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
-    x = shortcut + drop_path_apply(y.view(B, H * W, C), dp)
+    if debug is not None:                                      # embed_lamb = the LAST band's lambda (:277-296), [] without LFS
+        debug.append([before, visual_spectrum(y.reshape(B, H * W, C), H, W), lambs[-1] if lambs else []])
+    dp_attn, dp_mlp = drop_path_pair(dp)
+    x = shortcut + drop_path_apply(y.view(B, H * W, C), dp_attn)
     z = leff(st, p + 'mlp.', F.layer_norm(x, (C,), st[p + 'norm2.weight'], st[p + 'norm2.bias']))
-    return x + drop_path_apply(z, dp)
+    return x + drop_path_apply(z, dp_mlp)
 
 
 def tokens_to_img(x):
@@ -330,13 +355,18 @@ def run_layer(st, p, x, heads, depth, block_fn, dps, **kw):
 
 
 def uformer_decoder(st, p, opt, x, inter, dps=None):
-    """UformerDecoder.forward, decoder_Uformer.py:1117-1171 (all_* / plain path)."""
+    """UformerDecoder.forward, decoder_Uformer.py:1117-1171 (all_* / plain path).  With `opt.debug_mode` the return value is
+    (restored, visual_freqs), visual_freqs[layer][block] = [spectrum_before, spectrum_after, embed_lamb] (:1168-1169)."""
     lfs = lfs_config(opt.degradation_embedding_method)
     tab = {n: (h, d) for n, _, h, d, _ in decoder_layer_table(opt)}
     kw = dict(all_inter=inter, lfs=lfs)
+    visual = [] if getattr(opt, 'debug_mode', False) else None
 
     def layer(name, y):
         h, d = tab[name]
+        if visual is not None:
+            visual.append([])
+            return run_layer(st, f'{p}{name}.', y, h, d, lewin_block_dec, dps, debug=visual[-1], **kw)
         return run_layer(st, f'{p}{name}.', y, h, d, lewin_block_dec, dps, **kw)
 
     y = input_proj(st, p + 'input_proj.', x)
@@ -355,6 +385,8 @@ def uformer_decoder(st, p, opt, x, inter, dps=None):
     H = int(math.sqrt(L))
     y = F.conv2d(y.transpose(1, 2).view(B, C, H, H), st[p + 'output_proj.proj.0.weight'],
                  st[p + 'output_proj.proj.0.bias'], padding=1)
+    if visual is not None:
+        return x + y, visual
     return x + y
 
 
@@ -424,9 +456,10 @@ def lewin_block_enc(st, p, x, heads, shift, L, msa, dp=None):
     y = window_reverse(aw.view(-1, win, win, C), win, H, W)
     if shift > 0:
         y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
-    x = shortcut + drop_path_apply(y.view(B, H * W, C), dp)
+    dp_attn, dp_mlp = drop_path_pair(dp)
+    x = shortcut + drop_path_apply(y.view(B, H * W, C), dp_attn)
     z = leff(st, p + 'mlp.', F.layer_norm(x, (C,), st[p + 'norm2.weight'], st[p + 'norm2.bias']))
-    return x + drop_path_apply(z, dp)
+    return x + drop_path_apply(z, dp_mlp)
 
 
 def encoder_layer_table():

@@ -6,7 +6,7 @@ Imports the unmodified reference through ``oracle/refshim.py`` (timm stand-in, n
 inputs with DropPath neutralised and stores inputs + outputs as small ``.npz`` files
 (``numpy.load`` with ``allow_pickle=False`` reads them) plus the state-dict schema as JSON.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [unit] [model] [moco] [model256]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [unit] [model] [moco] [model256] [debug]
 
 A fixture is data (inputs / expected outputs); no reference source text is stored.
 """
@@ -275,6 +275,29 @@ def gen_model256():
     print('model256 done in %.1fs' % (time.time() - t0))
 
 
+def gen_debug():
+    """`opt.debug_mode = True` (plot_MSA_frequency.py:47, plot_embed_lamb_curve.py:48): the decoder returns (restored, visual_freqs),
+    visual_freqs[layer][block] = [spectrum of LN(x) before the attention, spectrum of the attention output, embed_lamb]
+    (decoder_Uformer.py:668-673,731-736,753-756,1168-1169).  Eval mode, all_3_bands, the seeded model of `model_all3`."""
+    set_opt(batch_size=2, degradation_embedding_method=['all_3_bands'], L=3, encoder_msa_type='freq', debug_mode=True)
+    try:
+        net = seed_module(AirNet(opt), '')
+    finally:
+        set_opt(debug_mode=False)
+    clean, q, k = synth_batch(2, 128, 'model.')
+    net.eval()
+    with torch.no_grad():
+        fea, inter = net.E(x_query=q, x_key=q)
+        restored, vf = net.R(x_query=q, inter=inter)
+    arrs = {'restored': restored, 'layers': np.array([len(layer) for layer in vf])}
+    for li, layer in enumerate(vf):
+        for bi, (before, after, lamb) in enumerate(layer):
+            arrs[f'before.{li}.{bi}'] = before
+            arrs[f'after.{li}.{bi}'] = after
+            arrs[f'lamb.{li}.{bi}'] = lamb
+    save('debug_all3', **arrs)
+
+
 def gen_moco():
     """Three consecutive train-mode steps of the encoder side only (net.E), SGD lr 0.05 on the
     query encoder in between, so that EMA, queue rotation and pointer wrap are all exercised."""
@@ -318,3 +341,5 @@ if __name__ == '__main__':
             gen_moco()
         if 'model256' in what:
             gen_model256()
+        if 'debug' in what:
+            gen_debug()

@@ -1,0 +1,298 @@
+"""Parity of the TIMED path -- `TrainEngine.step` as bench.py runs it (flat parameter / gradient buffers, kernels accumulating
+straight into the flat .grad views, fused [3C, C] QKV GEMMs, packed bias tables, deferred slab fold, whole-step HIP graph, key
+encoder on a side stream, fused Adam + EMA) -- against
+  (a) the goldens produced by the REAL reference (tests/golden/model_all3.npz: loss, 1 912 gradient norms, gradient tensors),
+  (b) torch.optim.Adam applied to the golden gradients,
+  (c) the CPU oracle at the timed batch size (B = 16) and over a short training run (loss curve, train.py:80-96).
+Reference lines: train.py:80-96 (step), net/model.py:59-71, net/utils/moco.py:115-166.
+Tolerances are max-abs-error / max-abs-reference ("rel-to-max", helpers.close); DropPath is neutralised as in the golden run,
+except in the test that injects recorded masks."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import airnet_oracle as O
+from helpers import close, load, make_opt, schema, synth_batch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def build(dtype='fp32', batch_size=2, queue=None):
+    from net.model import AirNet
+    from fwair import functional as Fn
+    Fn.config.direct_grads = False
+    opt = make_opt('all3', batch_size=batch_size, compute_dtype=dtype)
+    net = AirNet(opt)
+    st = O.fill_state_seeded(schema('all3'))
+    if queue is not None:
+        st['E.E.queue'] = queue
+    sd = net.state_dict()
+    for k in sd:
+        if st.get(k) is not None and sd[k].is_floating_point():
+            sd[k] = st[k]
+    net.load_state_dict(sd)
+    Fn.set_droppath_override(lambda name, n, rate, device: None)
+    return net.to(DEV).train(), opt, st
+
+
+def seeded_queue(B):
+    return torch.nn.functional.normalize(O.seeded_tensor('E.E.queue', (3, 256, 3 * B)) / 0.02, dim=1)
+
+
+def oracle_trainable(st):
+    names = [k for k in st if st[k] is not None and st[k].is_floating_point() and O.is_parameter_key(k)
+             and not k.startswith('E.E.encoder_k.')]
+    for n in names:
+        st[n] = st[n].clone().requires_grad_(True)
+    return names
+
+
+def engine_grads(eng, net):
+    """name -> gradient view of the engine's flat gradient buffer (what Adam consumed)."""
+    return {n: p.grad for n, p in net.named_parameters() if p.requires_grad and p.grad is not None}
+
+
+@pytest.mark.parametrize('graph', [True, False])
+def test_engine_step_fp32_matches_reference_golden(graph):
+    """One engine step (HIP graph replay / eager launches) on the inputs of the reference's golden train step."""
+    from fwair import engine as E
+    from fwair import functional as Fn
+    g = load('model_all3')
+    net, opt, _ = build('fp32')
+    p0 = {n: p.detach().clone().cpu() for n, p in net.named_parameters()}
+    eng = E.TrainEngine(net, lr=2e-4, contrast_loss_weight=0.6, use_graph=graph)
+    clean, q, k = synth_batch(2, 128, 'model.')
+    out = eng.step(q.to(DEV), k.to(DEV), clean.to(DEV))
+    torch.cuda.synchronize()
+    try:
+        e_loss = close(out[0], g['loss'], 1e-4, 'engine loss vs reference')
+        close(out[1], g['l1'], 1e-4, 'engine l1')
+        # with the seeded weights the contrastive term is ~6e-6 (log(1 + sum exp(l_neg - l_pos)) of a dominant positive): its own
+        # f32 rounding is 6e-3 of itself, so it is judged on the scale of the objective it is a term of
+        assert abs(float(out[2]) - float(g['contrast'])) < 1e-4 * float(g['loss']), 'engine contrast'
+        assert abs(float(out[2]) - float(g['contrast'])) < 2e-2 * float(g['contrast']), 'engine contrast (own scale)'
+        grads = engine_grads(eng, net)
+        names = [str(n) for n in g['grad_names']]
+        norms = torch.tensor([grads[n].norm().item() for n in names], dtype=torch.float64)
+        floor = float(g['grad_norms'].max()) * 1e-6
+        rel = (norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(floor)
+        # the lambda heads (attn.mlp_head / attn.mlp, norms 1e-9 .. 1e-6) hang off ONE scalar per (block, band, head) that sums 64x64
+        # cancelling terms over every window: they move by ~1e-3 with the order of the float atomics; everything else is judged 10x tighter
+        lam = torch.tensor(['.attn.mlp' in n for n in names])
+        worst, worst_o = int(rel.argmax()), int((rel * ~lam).argmax())
+        print(f'engine(graph={graph}) fp32: loss err {e_loss:.2e}; grad-norm deviation: lambda heads max {rel[lam].max():.2e} ({names[worst]}), '
+              f'all other parameters max {rel[~lam].max():.2e} ({names[worst_o]}), median {rel.median():.2e}')
+        assert rel[lam].max() < 5e-3, f'grad norm of {names[worst]}: {norms[worst]:.6e} vs {g["grad_norms"][worst]:.6e}'
+        assert rel[~lam].max() < 5e-4, f'grad norm of {names[worst_o]}: {norms[worst_o]:.6e} vs {g["grad_norms"][worst_o]:.6e}'
+        gmax = float(g['grad_norms'].max())
+        worst_t = 0.0
+        for key, val in g.items():
+            if key.startswith('g.'):
+                big = float(val.norm()) > 1e-6 * gmax
+                worst_t = max(worst_t, close(grads[key[2:]], val, 2e-3 if big else 5e-2, key) if big else 0.0)
+        print(f'engine(graph={graph}) fp32: worst gradient tensor rel-to-max err {worst_t:.2e}')
+        close(net.E.E.queue, g['queue_after'], 1e-4, 'queue after the step')
+        assert int(net.E.E.queue_ptr) == int(g['queue_ptr_after'])
+        # Adam (train.py:63,96): first step from zero moments, reference gradients -> p - lr * g / (|g| + eps)
+        lr, eps = 2e-4, 1e-8
+        checked = 0
+        for key, val in g.items():
+            if not key.startswith('g.'):
+                continue
+            n = key[2:]
+            ref = torch.optim.Adam([torch.nn.Parameter(p0[n].clone())], lr=lr)
+            ref.param_groups[0]['params'][0].grad = val.clone()
+            ref.step()
+            want = ref.param_groups[0]['params'][0].detach()
+            got = dict(net.named_parameters())[n].detach().cpu()
+            # Adam divides by |g| + 1e-8: well-conditioned only where |g| >> eps (the lambda heads' 1e-8 gradients are not), and the
+            # sign of a ~0 gradient is float-atomic ordering noise
+            solid = val.abs() > max(1e-2 * float(val.abs().max()), 1e-5)
+            if solid.any():
+                assert float((got - want)[solid].abs().max()) < 2e-6, f'Adam update of {n}'
+                checked += int(solid.sum())
+            assert float((got - p0[n]).abs().max()) <= lr * 1.001, f'Adam step size of {n}'
+        assert checked > 10000
+    finally:
+        Fn.config.direct_grads = False
+
+
+def test_engine_step_bf16_tracks_reference_golden():
+    """The bench configuration (bf16 operands, HIP graph) on the golden inputs: loss within 2 %, median gradient-norm deviation
+    below 5 % (bf16 keeps 8 significant bits; the median rule of test_model_gpu.py)."""
+    from fwair import engine as E
+    from fwair import functional as Fn
+    g = load('model_all3')
+    net, opt, _ = build('bf16')
+    eng = E.TrainEngine(net, lr=2e-4, contrast_loss_weight=0.6, use_graph=True)
+    clean, q, k = synth_batch(2, 128, 'model.')
+    out = eng.step(q.to(DEV), k.to(DEV), clean.to(DEV))
+    torch.cuda.synchronize()
+    try:
+        assert abs(float(out[0]) - float(g['loss'])) / float(g['loss']) < 2e-2
+        grads = engine_grads(eng, net)
+        names = [str(n) for n in g['grad_names']]
+        norms = torch.tensor([grads[n].norm().item() for n in names], dtype=torch.float64)
+        assert torch.isfinite(norms).all()
+        rel = (norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(1e-12)
+        big = g['grad_norms'] > g['grad_norms'].max() * 1e-3
+        print(f'engine bf16: loss {float(out[0]):.5f} vs {float(g["loss"]):.5f}; median grad-norm deviation {rel[big].median():.3e}')
+        assert rel[big].median() < 5e-2
+    finally:
+        Fn.config.direct_grads = False
+
+
+def test_engine_step_b16_matches_oracle():
+    """The TIMED batch size: one engine step at B = 16 (fp32 parity mode and the bf16 bench mode, HIP graph) against one CPU-oracle
+    step on the same 16 images -- loss, contrastive / L1 parts and a handful of gradients of all kinds (decoder, encoder body,
+    contrastive head, bias tables, lambda heads).  At this size the attention kernels loop over several items per workgroup,
+    the depthwise convolution takes its LDS-tiled form and the weight-gradient GEMMs split K further than at B = 2."""
+    from fwair import engine as E
+    from fwair import functional as Fn
+    B = 16
+    clean, q, k = synth_batch(B, 128, 'b16.')
+    res = {}
+    for dtype in ('fp32', 'bf16'):
+        net, opt, _ = build(dtype, batch_size=B, queue=seeded_queue(B))
+        eng = E.TrainEngine(net, lr=2e-4, contrast_loss_weight=0.6, use_graph=True)
+        out = eng.step(q.to(DEV), k.to(DEV), clean.to(DEV))
+        torch.cuda.synchronize()
+        grads = {n: v.detach().clone().cpu() for n, v in engine_grads(eng, net).items()}
+        res[dtype] = (out.detach().cpu().clone(), grads)
+        Fn.config.direct_grads = False
+        del eng, net
+        torch.cuda.empty_cache()
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    st = O.fill_state_seeded(schema('all3'))
+    st['E.E.queue'] = seeded_queue(B)
+    opt = make_opt('all3', batch_size=B)
+    names = oracle_trainable(st)
+    restored, logits, labels = O.airnet_forward(st, opt, q, k, True)
+    loss, l1, contrast = O.training_loss(opt, restored, logits, labels, clean)
+    loss.backward()
+    out, grads = res['fp32']
+    e = close(out[0], loss, 1e-4, 'B=16 fp32 engine loss vs oracle')
+    close(out[1], l1, 1e-4, 'B=16 l1')
+    assert abs(float(out[2]) - float(contrast)) < 1e-4 * float(loss), 'B=16 contrast (a ~5e-5 term of the objective: judged on its scale)'
+    assert abs(float(out[2]) - float(contrast)) < 2e-2 * float(contrast), 'B=16 contrast (own scale)'
+    probe = ['R.R.output_proj.proj.0.weight', 'R.R.encoderlayer_0.blocks.1.attn.qkv.to_q.weight',
+             'R.R.decoderlayer_0.blocks.1.mlp.conv.0.weight', 'R.R.decoderlayer_0.blocks.0.mlp.linear1.0.weight',
+             'R.R.decoderlayer_0.blocks.1.attn.relative_position_bias_table', 'R.R.bottleneck_0.blocks.0.attn.proj.weight',
+             'R.R.decoderlayer_2.blocks.3.attn.mlp_head.1.1.weight', 'R.R.dowsample_0.conv.0.weight', 'R.R.upsample_0.deconv.0.weight',
+             'E.E.encoder_q.uformer.encoderlayer_0.blocks.1.attn_inter.relative_position_bias_table.1',
+             'E.E.encoder_q.uformer.encoderlayer_0.blocks.0.mlp.conv.0.weight', 'E.E.encoder_q.uformer.conv.blocks.1.attn_inter.proj.weight',
+             'E.E.encoder_q.mlp_head.0.1.bias', 'E.E.encoder_q.mlp.1.2.weight', 'E.E.encoder_q.uformer.input_proj.proj.0.weight']
+    gmax = max(float(st[n].grad.norm()) for n in names if st[n].grad is not None)
+    worst = 0.0
+    for n in probe:
+        ref = st[n].grad
+        tol = 2e-3 if float(ref.norm()) > 1e-6 * gmax else 5e-2
+        worst = max(worst, close(grads[n], ref, tol, 'B=16 grad ' + n))
+    print(f'B=16 fp32 engine vs oracle: loss err {e:.2e}, worst probed gradient err {worst:.2e}')
+    out16, g16 = res['bf16']
+    assert abs(float(out16[0]) - float(loss)) / float(loss) < 2e-2, (float(out16[0]), float(loss))
+    dev = []
+    for n in probe:
+        ref = st[n].grad
+        if float(ref.norm()) > 1e-3 * gmax:
+            dev.append(abs(float(g16[n].norm()) - float(ref.norm())) / float(ref.norm()))
+    print(f'B=16 bf16 engine vs oracle: loss {float(out16[0]):.5f} vs {float(loss):.5f}; grad-norm deviations {np.round(dev, 4).tolist()}')
+    assert float(np.median(dev)) < 5e-2
+
+
+def test_engine_loss_curve_tracks_oracle_adam():
+    """a short training run (6 steps, B = 2, fp32, DropPath off, a new batch every step) of the fused engine
+    (graph replay, fused Adam, EMA key encoder, rotating MoCo queue) against the oracle + torch.optim.Adam loop of train.py:80-96.
+    fp32: every loss within 1e-4 relative; bf16: within 2 %."""
+    from fwair import engine as E
+    from fwair import functional as Fn
+    steps = 6
+    batches = [synth_batch(2, 128, f'curve{s}.') for s in range(steps)]
+    curves = {}
+    for dtype in ('fp32', 'bf16'):
+        net, opt, _ = build(dtype)
+        eng = E.TrainEngine(net, lr=2e-4, contrast_loss_weight=0.6, use_graph=True)
+        cur = []
+        for clean, q, k in batches:
+            cur.append(eng.step(q.to(DEV), k.to(DEV), clean.to(DEV)).detach().cpu().clone())
+        torch.cuda.synchronize()
+        curves[dtype] = torch.stack(cur)
+        if dtype == 'fp32':
+            p_end = {n: p.detach().cpu().clone() for n, p in net.named_parameters() if p.requires_grad}
+            k_end = {n: p.detach().cpu().clone() for n, p in net.E.E.encoder_k.named_parameters()}
+            queue_end = net.E.E.queue.detach().cpu().clone()
+        Fn.config.direct_grads = False
+        del eng, net
+    st = O.fill_state_seeded(schema('all3'))
+    opt = make_opt('all3', batch_size=2)
+    names = oracle_trainable(st)
+    optim = torch.optim.Adam([st[n] for n in names], lr=2e-4)
+    ref = []
+    for clean, q, k in batches:
+        optim.zero_grad()
+        restored, logits, labels = O.airnet_forward(st, opt, q, k, True)
+        loss, l1, contrast = O.training_loss(opt, restored, logits, labels, clean)
+        loss.backward()
+        optim.step()
+        ref.append(torch.stack([loss.detach(), l1.detach(), contrast.detach()]))
+    ref = torch.stack(ref)
+    # every component (total, l1, contrast) on the scale of the step's objective: the contrastive term of step 0 is ~6e-6
+    err32 = ((curves['fp32'] - ref).abs() / ref[:, :1].abs()).max(1).values
+    err16 = ((curves['bf16'] - ref).abs() / ref[:, :1].abs()).max(1).values
+    print('oracle   loss curve:', [round(float(v), 6) for v in ref[:, 0]])
+    print('fp32 HIP loss curve:', [round(float(v), 6) for v in curves['fp32'][:, 0]], 'rel err per step', [f'{float(v):.1e}' for v in err32])
+    print('bf16 HIP loss curve:', [round(float(v), 6) for v in curves['bf16'][:, 0]], 'rel err per step', [f'{float(v):.1e}' for v in err16])
+    assert float(err32.max()) < 1e-4, 'fp32 loss curve leaves the oracle'
+    assert float(err16.max()) < 2e-2, 'bf16 loss curve leaves the band'
+    close(queue_end, st['E.E.queue'], 1e-3, 'MoCo queue after 6 steps')
+    # parameters after 6 Adam steps: every step moves a weight by <= lr, so compare the bulk (a ~0 gradient's sign is noise)
+    for n in ('R.R.output_proj.proj.0.weight', 'R.R.decoderlayer_0.blocks.0.mlp.linear1.0.weight', 'E.E.encoder_q.mlp.0.2.weight'):
+        d = (p_end[n] - st[n].detach()).abs()
+        assert float(d.median()) < 2e-6 and float((d > 1e-4).float().mean()) < 0.02, f'{n} after {steps} Adam steps'
+    n = 'uformer.conv.blocks.1.mlp.linear2.0.weight'
+    close(k_end[n], st['E.E.encoder_k.' + n], 1e-4, 'EMA key-encoder weight after 6 steps')
+
+
+def test_two_droppath_masks_per_block_match_oracle():
+    """The reference calls self.drop_path twice per block (decoder_Uformer.py:739,751; encoder_Uformer.py:679-680): independent
+    masks for the attention branch and for the MLP branch.  Recorded masks (different for the two branches) are injected into
+    the HIP path and into the oracle; outputs, loss and gradients must agree."""
+    from fwair import functional as Fn
+    net, opt, st = build('fp32')
+    rec = {}
+
+    def masks(name, n, rate, device):
+        rs = np.random.RandomState(zlib.crc32(('dp.' + name).encode()) & 0x7fffffff)
+        keep = 1.0 - rate
+        # rate is at most 0.1: force some drops so that every stage really sees both values
+        m = torch.from_numpy(np.floor(keep - 0.25 + rs.uniform(size=n)).clip(0, 1).astype(np.float32)) / keep
+        rec[name] = m
+        return m.to(device)
+
+    Fn.set_droppath_override(masks)
+    try:
+        clean, q, k = synth_batch(2, 128, 'dp2.')
+        restored, logits, labels = net(x_query=q.to(DEV), x_key=k.to(DEV))
+        CE = torch.nn.CrossEntropyLoss()
+        loss = torch.nn.L1Loss()(restored, clean.to(DEV)) + 0.6 * sum(CE(logits[i], labels[i]) for i in range(3)) / 3
+        loss.backward()
+    finally:
+        Fn.set_droppath_override(lambda name, n, rate, device: None)
+    pref = sorted({n[:-4] if n.endswith('attn') else n[:-3] for n in rec})
+    assert all(p + 'attn' in rec and p + 'mlp' in rec for p in pref)
+    assert any(not torch.equal(rec[p + 'attn'], rec[p + 'mlp']) for p in pref), 'the two branches must be able to differ'
+    dps = {p: (rec[p + 'attn'], rec[p + 'mlp']) for p in pref}
+    names = oracle_trainable(st)
+    r2, lg2, lb2 = O.airnet_forward(st, opt, q, k, True, dps=dps)
+    loss2, _, _ = O.training_loss(opt, r2, lg2, lb2, clean)
+    loss2.backward()
+    close(restored, r2, 1e-4, 'restored with two masks per block')
+    close(loss, loss2, 1e-4, 'loss with two masks per block')
+    params = dict(net.named_parameters())
+    for n in ('R.R.decoderlayer_0.blocks.1.mlp.linear2.0.weight', 'R.R.encoderlayer_2.blocks.3.attn.proj.weight',
+              'E.E.encoder_q.uformer.encoderlayer_1.blocks.1.mlp.linear1.0.weight',
+              'E.E.encoder_q.uformer.conv.blocks.0.attn_inter.proj.weight'):
+        close(params[n].grad, st[n].grad, 2e-3, 'grad ' + n)

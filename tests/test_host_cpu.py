@@ -27,6 +27,10 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r' T (fw_\w+)', nm))
     assert declared <= exported, declared - exported
     assert lib.lib().fw_attn_lfs_table_elems() == 29696
+    # the package's own copy of the header (made by build.sh, what lib.py parses) is the repository's include/fwair.h
+    own = os.path.join(PKG, 'fwair', 'fwair.h')
+    if os.path.exists(own):
+        assert open(own).read() == open(os.path.join(ROOT, 'include', 'fwair.h')).read(), 'stale fwair/fwair.h: re-run build.sh'
 
 
 @pytest.mark.parametrize('variant', list(VARIANTS))

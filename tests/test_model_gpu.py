@@ -241,3 +241,44 @@ def test_256_resolution_fp32_and_bf16():
     rel = ((norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(1e-12))
     big = g['grad_norms'] > g['grad_norms'].max() * 1e-3
     assert rel[big].median() < 5e-2, f'median relative grad-norm deviation {rel[big].median():.3e}'
+
+
+def test_debug_mode_payload():
+    """`opt.debug_mode = True` (plot_MSA_frequency.py:47, plot_embed_lamb_curve.py:48) -> the decoder returns
+    (restored, visual_freqs), visual_freqs[layer][block] = [spectrum_before [H, W], spectrum_after [H, W], embed_lamb [B, 1, heads]]
+    (decoder_Uformer.py:668-673,731-736,753-756,1168-1169); against the golden produced by the reference in debug mode."""
+    from net.model import AirNet
+    from fwair import functional as Fn
+    g = load('debug_all3')
+    opt = make_opt('all3', debug_mode=True)
+    net = AirNet(opt)
+    st = O.fill_state_seeded(schema('all3'))
+    sd = net.state_dict()
+    assert len(sd) == 2496                                    # the debug modules add no state
+    for k in sd:
+        if st.get(k) is not None and sd[k].is_floating_point():
+            sd[k] = st[k]
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    clean, q, k = synth_batch(2, 128, 'model.')
+    with torch.no_grad():
+        fea, inter = net.E(x_query=q.to(DEV), x_key=q.to(DEV))
+        restored, vf = net.R(x_query=q.to(DEV), inter=inter)
+        both = net(x_query=q.to(DEV), x_key=q.to(DEV))        # AirNet.forward hands the tuple through (net/model.py:66-71)
+    assert isinstance(both, tuple) and len(both) == 2
+    close(restored, g['restored'], 1e-4, 'restored (debug mode)')
+    assert [len(layer) for layer in vf] == g['layers'].tolist()
+    worst = 0.0
+    for li, layer in enumerate(vf):
+        for bi, (before, after, lamb) in enumerate(layer):
+            assert before.shape == g[f'before.{li}.{bi}'].shape
+            worst = max(worst, close(before, g[f'before.{li}.{bi}'], 1e-4, f'spectrum before {li}.{bi}'))
+            worst = max(worst, close(after, g[f'after.{li}.{bi}'], 1e-4, f'spectrum after {li}.{bi}'))
+            worst = max(worst, close(lamb, g[f'lamb.{li}.{bi}'], 1e-4, f'embed_lamb {li}.{bi}'))
+    print(f'debug payload: worst rel-to-max err {worst:.2e}')
+    # the plain decoder (degradation_embedding_method None, as plot_MSA_frequency.py:42 sets it): embed_lamb is [] there
+    opt2 = make_opt('all3', debug_mode=True, degradation_embedding_method=['None'])
+    net2 = AirNet(opt2).to(DEV).eval()
+    with torch.no_grad():
+        r2, vf2 = net2.R(x_query=q.to(DEV), inter=[0, 0, 0, 0, 0, [0, 0, 0, 0, 0]])
+    assert r2.shape == q.shape and len(vf2) == 10 and vf2[0][0][2] == [] and vf2[0][0][0].shape == (128, 128)

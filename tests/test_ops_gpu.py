@@ -635,3 +635,88 @@ def test_lfs_lambda_heads(nb, NT):
     dinter = torch.zeros(nb1 * B, NT, C, device=DEV)
     call('fw_lfs_xbar_bwd', idev, stats, dxbar, dinter, nb1, B, NT, C)
     close(dinter, inter.grad, 2e-4, 'dinter')
+
+
+# ------------------------------------------------------------------------------------------------ shapes of the TIMED step (B = 16)
+# The bench runs B = 16 at 128x128.  At that size three code paths fire that the small cases above never reach:
+#   * fw_attn_fwd caps its grid at 4 096 workgroups and LOOPS over items (with a trailing barrier between items),
+#   * fw_attn_bwd's chunks walk many windows per workgroup, accumulating the bias gradient across them,
+#   * fw_dwconv_fwd / _bwd switch to the LDS-tiled kernel (dwconv_tile_kernel) once B*H*W*C >= 80 M elements.
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_attention_decoder_timed_shape(dtype):
+    """decoderlayer_0 of the timed step: B = 16, 128x128, C = 112, 2 heads, LFS (3 bands), shifted -> 8 192 items > the 4 096 cap."""
+    B, H, W, heads, shift, lfs, nb = 16, 128, 128, 2, 4, 2, 3
+    C = 56 * heads
+    qkv = q(rnd(B * H * W, 3 * C), dtype).requires_grad_(True)
+    tables = (rnd(1, 225, heads, seed=1) * 0.5).requires_grad_(True)
+    lam = (rnd(B, nb - 1, heads, seed=2) * 0.3).requires_grad_(True)
+    ref = ref_window_attention(qkv, C, B, H, W, heads, 1, 0, shift, tables, lam, nb)
+    coef = lam_to_coef(lam, nb).detach().to(DEV).contiguous()
+    qd = qkv.detach().to(DEV, dtype)
+    out, lse = ops().attn_fwd(qd, C, B, H, W, heads, 1, 0, shift, tables.detach().to(DEV), coef, lfs)
+    close(out, ref, TOL[dtype], 'out (8192 items)')
+    dout = q(rnd(B * H * W, C, seed=3), dtype)
+    ref.backward(dout)
+    lam_grad_ref = lam.grad.clone()
+    dbias = torch.zeros(1, 225, heads, device=DEV)
+    dcoef = torch.zeros(B, heads, 3, device=DEV)
+    dqkv = ops().attn_bwd(qd, out, dout.to(DEV, dtype), lse, C, B, H, W, heads, 1, 0, shift, tables.detach().to(DEV), dbias, coef, dcoef, lfs)
+    tol = TOL[dtype] * (3 if dtype == torch.bfloat16 else 4)
+    close(dqkv, qkv.grad, tol, 'dqkv (8192 items)')
+    close(dbias, tables.grad, tol * 2, 'dbias table summed over 4096 windows')
+    lam.grad = None
+    (lam_to_coef(lam, nb) * dcoef.cpu()).sum().backward()
+    close(lam.grad, lam_grad_ref, tol * 2, 'dlambda summed over 256 windows per image')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('mode', [0, 1])
+def test_attention_encoder_timed_shape(dtype, mode):
+    """encoderlayer_0 of the query encoder in the timed step: L = 3 bands x B = 16 images, 128x128, C = 28, 1 head, shifted:
+    12 288 items (intra) / 12 288 items with two key tiles (inter)."""
+    L, B, H, W, heads, shift = 3, 16, 128, 128, 1, 4
+    C = 28 * heads
+    qkv = q(rnd(L * B * H * W, 3 * C), dtype)
+    ld = (3 * C + 7) // 8 * 8
+    tables = (rnd(L * L, 225, heads, seed=1) * 0.5).requires_grad_(True)
+    qr = qkv.clone().requires_grad_(True)
+    ref = ref_window_attention(qr, C, B, H, W, heads, L, mode, shift, tables)
+    buf = torch.zeros(L * B * H * W, ld, device=DEV, dtype=dtype)
+    buf[:, :3 * C] = qkv.to(DEV, dtype)
+    qd = buf[:, :3 * C]
+    out, lse = ops().attn_fwd(qd, C, B, H, W, heads, L, mode, shift, tables.detach().to(DEV))
+    close(out, ref, TOL[dtype], 'out (12288 items)')
+    dout = q(rnd(L * B * H * W, C, seed=3), dtype)
+    ref.backward(dout)
+    dbias = torch.zeros(L * L, 225, heads, device=DEV)
+    dbuf = torch.zeros(L * B * H * W, (C + 7) // 8 * 8, device=DEV, dtype=dtype)
+    dbuf[:, :C] = dout.to(DEV, dtype)
+    dqkv = ops().attn_bwd(qd, out, dbuf[:, :C], lse, C, B, H, W, heads, L, mode, shift, tables.detach().to(DEV), dbias)
+    tol = TOL[dtype] * 4
+    close(dqkv, qr.grad, tol, 'dqkv (12288 items)')
+    close(dbias, tables.grad, tol * 2, 'dbias tables summed over 4096 windows')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_dwconv_tiled_kernel_timed_shape(dtype):
+    """LeFF depthwise 3x3 of decoderlayer_0 in the timed step: B = 16, 128x128, hidden 448 -> 117 M elements >= the 80 M threshold
+    of fw_dwconv_fwd / fw_dwconv_bwd, so dwconv_tile_kernel<*, 0> (forward + GELU twin) and <*, 1> (data gradient) run."""
+    B, H, W, C = 16, 128, 128, 448
+    assert B * H * W * C >= 80_000_000
+    h1 = q(rnd(B * H * W, C), dtype).requires_grad_(True)
+    w = (rnd(C, 1, 3, 3, seed=1) * 0.3).requires_grad_(True)
+    b = (rnd(C, seed=2) * 0.1).requires_grad_(True)
+    g1 = q(F.gelu(h1.detach()), dtype)
+    ref = F.conv2d(F.gelu(h1).view(B, H, W, C).permute(0, 3, 1, 2), w, b, padding=1, groups=C).permute(0, 2, 3, 1).reshape(B * H * W, C)
+    wt = w.detach().view(C, 9).t().contiguous().to(DEV)
+    h2, g2 = ops().dwconv_fwd(g1.to(DEV, dtype), wt, b.detach().to(DEV), B, H, W)
+    close(h2, ref, TOL[dtype], 'h2 (tiled kernel)')
+    close(g2, F.gelu(ref.detach()), TOL[dtype], 'g2 (tiled kernel)')
+    dh2 = q(rnd(B * H * W, C, seed=3), dtype)
+    ref.backward(dh2)
+    dw, db = torch.zeros(C, 9, device=DEV), torch.zeros(C, device=DEV)
+    dh1 = ops().dwconv_bwd(dh2.to(DEV, dtype), g1.to(DEV, dtype), h1.detach().to(DEV, dtype), wt, dw, db, B, H, W)
+    close(dh1, h1.grad, TOL[dtype] * 2, 'dh1 (tiled kernel)')
+    # 262 144 pixels summed per tap: f32 atomics of block partials; bf16 operands carry 8 bits each
+    close(dw, w.grad.view(C, 9), TOL[dtype] * 4, 'dw')
+    close(db, b.grad, TOL[dtype] * 4, 'db')

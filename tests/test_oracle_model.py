@@ -72,3 +72,21 @@ def test_256_eval_and_train_step():
     for key, val in g.items():
         if key.startswith('g.'):
             close(st[key[2:]].grad, val, 2e-3, key)
+
+
+def test_debug_mode_payload():
+    """`opt.debug_mode` (plot_MSA_frequency.py:47, plot_embed_lamb_curve.py:48): (restored, visual_freqs) with one
+    [spectrum_before, spectrum_after, embed_lamb] per block (decoder_Uformer.py:668-673,731-736,753-756,1168-1169)."""
+    g = load('debug_all3')
+    st = O.fill_state_seeded(schema('all3'))
+    opt = make_opt('all3', debug_mode=True)
+    clean, q, k = synth_batch(2, 128, 'model.')
+    with torch.no_grad():
+        restored, vf = O.airnet_forward(st, opt, q, q, False)
+    close(restored, g['restored'], 1e-4, 'restored')
+    assert [len(layer) for layer in vf] == g['layers'].tolist() == [2, 2, 8, 8, 2, 2, 8, 8, 2, 2]
+    for li, layer in enumerate(vf):
+        for bi, (before, after, lamb) in enumerate(layer):
+            close(before, g[f'before.{li}.{bi}'], 1e-4, f'spectrum before {li}.{bi}')
+            close(after, g[f'after.{li}.{bi}'], 1e-4, f'spectrum after {li}.{bi}')
+            close(lamb, g[f'lamb.{li}.{bi}'], 1e-4, f'embed_lamb {li}.{bi}')

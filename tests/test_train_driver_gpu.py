@@ -16,7 +16,7 @@ PKG = os.path.join(ROOT, 'frequency-wised_all-in-one_image_restoration_model_amd
 def run(out, *extra):
     cmd = [sys.executable, os.path.join(PKG, 'train_ddp.py'), '--de_type', 'denoising_25', '--degradation_embedding_method', 'all_3_bands',
            '--contrast_loss_weight', '0.6', '--compute_dtype', 'bf16', '--per_gpu_batch', '2', '--synthetic_steps', '2',
-           '--output_path', out, '--epochs_encoder', '1', *extra]
+           '--output_path', out, '--epochs_encoder', '1', '--test_de_type', 'denoising_bsd68_25', 'deraining', *extra]
     r = subprocess.run(cmd, cwd=PKG, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return r.stdout
@@ -30,6 +30,11 @@ def test_two_phase_training_and_resume(tmp_path):
     assert re.fullmatch(r'Epoch \(1\)  Loss: l1_loss:\d+\.\d{4} contrast_loss:\d+\.\d{4}', log[1])    # train.py:107-117
     assert len(log) == 3
     assert os.path.exists(out + 'options.log')
+    res = open(out + 'results.log').read().splitlines()                                                # train.py:131-139
+    assert res[0] == '2 Epochs Results:' and res[3] == '3 Epochs Results:' and len(res) == 6
+    m = re.fullmatch(r'denoising_bsd68_25: {8}PSNR/SSIM: (\d+\.\d{2})/nan', res[1])
+    assert m and 5 < float(m.group(1)) < 60, res[1]
+    assert res[2].startswith('deraining: ' + ' ' * 16 + 'PSNR/SSIM: ')
     for e in (2, 3):
         assert os.path.exists(out + f'ckpt/epoch_{e}.pth') and os.path.exists(out + f'ckpt/epoch_{e}.opt.pth')
     sd = torch.load(out + 'ckpt/epoch_3.pth', map_location='cpu', weights_only=True)

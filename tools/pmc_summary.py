@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py -> HBM bytes per launch of the GEMM kernels.
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py -> HBM bytes per launch of the hot kernels.
 
-    tools/pmc_summary.py <fetch_dir> <write_dir> <out.json>
+    tools/pmc_summary.py <fetch_dir> <write_dir> <out.json> [commit] [date]
 
-FETCH_SIZE / WRITE_SIZE are reported in KiB-sized units of 1024 bytes by rocprofv3's derived counters; on gfx950 FETCH_SIZE
-tallies the 128-byte requests of wide coalesced reads at 64 bytes, so it is doubled (MI355X_MICROARCH.md, section HBM)."""
+FETCH_SIZE / WRITE_SIZE are reported in units of 1024 bytes by rocprofv3's derived counters; on gfx950 FETCH_SIZE tallies the
+128-byte requests of wide coalesced reads at 64 bytes, so it is doubled (MI355X_MICROARCH.md, section HBM).
+A pass that produced no rows for a counter is an ERROR (exit 2): a crashed profiling run must not turn into zeros."""
 import collections
 import csv
 import glob
@@ -14,14 +15,20 @@ import sys
 
 
 def per_kernel(d, counter):
-    f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
+    files = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
+    if not files:
+        sys.exit(f'pmc_summary: no *counter_collection.csv under {d!r} -- the {counter} pass did not complete')
     acc = collections.defaultdict(lambda: [0.0, 0])
-    for path in f:
+    rows = 0
+    for path in files:
         for r in csv.DictReader(open(path)):
             if r.get('Counter_Name') != counter:
                 continue
+            rows += 1
             acc[r['Kernel_Name']][0] += float(r['Counter_Value'])
             acc[r['Kernel_Name']][1] += 1
+    if rows == 0:
+        sys.exit(f'pmc_summary: {len(files)} file(s) under {d!r} hold no {counter} rows -- wrong directory or a failed pass')
     return acc
 
 
@@ -30,29 +37,47 @@ def short(name):
     if m:
         return f'gemm_tr_kernel<xT={int(m.group(1) == "true")}>'
     m = re.search(r'gemm_(stream_)?kernel<([^>]*)>', name)
-    if not m:
-        return None
-    a = [x.strip() for x in m.group(2).split(',')]
-    dt = 'bf16' if a[0] == 'unsigned short' else 'f32'
-    if m.group(1):
-        return f'gemm_stream_kernel<{dt},wT={int(a[2] == "true")}>'
-    return f'gemm_kernel<{dt},BN={a[1]},xT={int(a[2] == "true")},wT={int(a[3] == "true")}>'
+    if m:
+        a = [x.strip() for x in m.group(2).split(',')]
+        dt = 'bf16' if a[0] == 'unsigned short' else 'f32'
+        if m.group(1):
+            return f'gemm_stream_kernel<{dt},wT={int(a[2] == "true")}>'
+        return f'gemm_kernel<{dt},BN={a[1]},xT={int(a[2] == "true")},wT={int(a[3] == "true")}>'
+    m = re.search(r'(attn_fwd_kernel|attn_bwd_kernel|dwconv_\w+_kernel|ln_fwd_kernel|ln_bwd_kernel|leff_\w+_kernel|slab_reduce_multi_kernel'
+                  r'|adam_kernel|ema_kernel)(<[^>]*>)?', name)
+    if m:
+        return (m.group(1) + (m.group(2) or '')).replace('unsigned short', 'bf16').replace(' ', '')
+    return None
 
 
-fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
-out = {}
-agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
-for name, (v, n) in fetch.items():
-    k = short(name)
-    if k:
-        agg[k][0] += v; agg[k][2] += n
-for name, (v, n) in write.items():
-    k = short(name)
-    if k:
-        agg[k][1] += v
-for k, (fv, wv, n) in agg.items():
-    out[k] = {'launches': n, 'fetch_kib_raw_per_launch': fv / n, 'write_kib_per_launch': wv / n,
-              'hbm_bytes_per_launch': int((2.0 * fv + wv) * 1024 / n)}
-json.dump(out, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
-for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches']):
-    print(f"{k:45s} launches {v['launches']:6d}  HBM bytes/launch {v['hbm_bytes_per_launch'] / 1e6:9.2f} MB")
+def main():
+    if len(sys.argv) < 4:
+        sys.exit(__doc__)
+    fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
+    agg = collections.defaultdict(lambda: [0.0, 0.0, 0, 0])
+    for name, (v, n) in fetch.items():
+        k = short(name)
+        if k:
+            agg[k][0] += v; agg[k][2] += n
+    for name, (v, n) in write.items():
+        k = short(name)
+        if k:
+            agg[k][1] += v; agg[k][3] += n
+    kernels = {}
+    for k, (fv, wv, nf, nw) in agg.items():
+        if nf == 0 or nw == 0:
+            print(f'pmc_summary: {k}: seen in only one pass (fetch launches {nf}, write launches {nw}) -- skipped', file=sys.stderr)
+            continue
+        kernels[k] = {'launches_fetch_pass': nf, 'launches_write_pass': nw, 'fetch_kib_raw_per_launch': fv / nf,
+                      'write_kib_per_launch': wv / nw, 'hbm_bytes_per_launch': int((2.0 * fv / nf + wv / nw) * 1024)}
+    doc = {'commit': sys.argv[4] if len(sys.argv) > 4 else None, 'collected': sys.argv[5] if len(sys.argv) > 5 else None,
+           'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of bench.py; bytes = 2 * FETCH_SIZE * 1024 '
+                     '(gfx950 correction) + WRITE_SIZE * 1024, per launch', 'kernels': kernels}
+    json.dump(doc, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches_fetch_pass']):
+        print(f"{k:60s} launches {v['launches_fetch_pass']:6d}  read {2.048e-3 * v['fetch_kib_raw_per_launch']:9.2f} MB  "
+              f"write {1.024e-3 * v['write_kib_per_launch']:9.2f} MB per launch")
+
+
+if __name__ == '__main__':
+    main()

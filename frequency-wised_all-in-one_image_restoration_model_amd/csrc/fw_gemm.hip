@@ -45,6 +45,14 @@ constexpr int LDS_ROW = 128;            // 128 B of K per row, XOR-swizzled in 1
 FW_DEV int swz(int row) { return ((row ^ (row >> 3)) & 7) << 4; }
 constexpr int BM = 128;
 
+// Workgroups are dealt round-robin to the 8 XCDs (8 private L2s): block `lin` of `total` -> position in an order where every
+// XCD owns one CONTIGUOUS share (bijective for any total: the first total % 8 XCDs take one block more;
+// cdna_hip_programming.md 5.5 T1).  Speed only, never correctness.
+FW_DEV unsigned xcd_contiguous(unsigned lin, unsigned total) {
+    const unsigned xcd = lin & 7, q = total >> 3, r = total & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+}
+
 template <typename T> FW_DEV uint4 apply_gelu16(const uint4& v) {
     float f[TT<T>::E16];
     unpack16<T>(v, f);
@@ -285,18 +293,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     {
         const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-        if (gridDim.z > 1 && (total & 7) == 0) {
+        if (gridDim.z > 1) {
             const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            const unsigned w = xcd_contiguous(lin, total);
             bx = (int)(w % gridDim.x);
             by = (int)((w / gridDim.x) % gridDim.y);
             bz = (int)(w / (gridDim.x * gridDim.y));
-        } else if (gridDim.z == 1 && gridDim.y > 1 && (total & 7) == 0) {
+        } else if (gridDim.z == 1 && gridDim.y > 1) {
             // no split-K: every XCD takes a contiguous eighth of a GROUPED tile order (bands of 8 m tiles, n tiles swept inside a
             // band), so the ~64 tiles an XCD has in flight touch 8 x 8 operand panels that fit its 4 MB L2 instead of re-fetching
             // X once per n tile (PMC: 2.5x the algorithmic bytes crossed the fabric in plain row-major order)
             const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            const unsigned w = xcd_contiguous(lin, total);
             const unsigned per_band = 8 * gridDim.y;
             const unsigned band = w / per_band, first = band * 8;
             const unsigned gsz = min(gridDim.x - first, 8u);
@@ -453,18 +461,18 @@ __global__ __launch_bounds__(256) void gemm_tr_kernel(GemmArgs a) {
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     {                                                     // contiguous eighths of the (slice, n tile, m tile) order per XCD, see gemm_kernel
         const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-        if (gridDim.z > 1 && (total & 7) == 0) {
+        if (gridDim.z > 1) {
             const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            const unsigned w = xcd_contiguous(lin, total);
             bx = (int)(w % gridDim.x);
             by = (int)((w / gridDim.x) % gridDim.y);
             bz = (int)(w / (gridDim.x * gridDim.y));
-        } else if (gridDim.z == 1 && gridDim.y > 1 && (total & 7) == 0) {
+        } else if (gridDim.z == 1 && gridDim.y > 1) {
             // no split-K: every XCD takes a contiguous eighth of a GROUPED tile order (bands of 8 m tiles, n tiles swept inside a
             // band), so the ~64 tiles an XCD has in flight touch 8 x 8 operand panels that fit its 4 MB L2 instead of re-fetching
             // X once per n tile (PMC: 2.5x the algorithmic bytes crossed the fabric in plain row-major order)
             const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            const unsigned w = xcd_contiguous(lin, total);
             const unsigned per_band = 8 * gridDim.y;
             const unsigned band = w / per_band, first = band * 8;
             const unsigned gsz = min(gridDim.x - first, 8u);
@@ -570,33 +578,55 @@ FW_DEV void glds16_asm(const char* gsrc, char* lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
-// one [KT tokens][128 cols] tile of a token-major operand; a wave-instruction fills 4 token rows (1 KB, lane-linear)
-template <int KT>
-FW_DEV void glds_issue_km_t(const char* base, long ld, int col0, int cols_total, int k0, char* tile) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Source pointers of a thread's LDS-DMA instructions for stage 0, computed ONCE (row * ld + swizzled column: 64-bit multiplies);
+// a later stage only adds its K offset.  (Recomputed per stage, the address arithmetic was ~15 VALU instructions per 1 KB moved.)
+// Token-major operand: one [KT tokens][128 cols] tile, a wave-instruction fills 4 token rows (1 KB, lane-linear).
+template <int KT> struct GldsKm {
+    static constexpr int NI = KT / 16;
+    const char* src[NI];
+    long kstride;                                        // bytes per token row
+    int loff[NI];                                        // LDS byte offset of the instruction's 1 KB inside the tile
+    FW_MEM void init(const char* base, long ld, int col0, int cols_total, int k0) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        kstride = ld * 2;
 #pragma unroll
-    for (int it = 0; it < KT / 16; ++it) {
-        const int R0 = wave * (KT / 4) + it * 4;
-        const int r = R0 + (lane >> 4), p = lane & 15;
-        int col = col0 + ((p ^ swz256(r)) << 3);
-        if (col >= cols_total) col = 0;
-        const char* g = base + ((long)(k0 + r) * ld + col) * 2;
-        glds16_asm(g, tile + R0 * 256);
+        for (int it = 0; it < NI; ++it) {
+            const int R0 = wave * (KT / 4) + it * 4;
+            const int r = R0 + (lane >> 4), p = lane & 15;
+            int col = col0 + ((p ^ swz256(r)) << 3);
+            if (col >= cols_total) col = 0;                // columns past the matrix only feed masked outputs; stay inside the row
+            src[it] = base + ((long)(k0 + r) * ld + col) * 2;
+            loff[it] = R0 * 256;
+        }
     }
-}
-// the k-contiguous image of gemm_kernel ([ROWS][128 B], slot swizzle on the source address), asm-issued
-template <typename T, int ROWS>
-FW_DEV void glds_issue_asm(const char* base, long ld, int row0, int rows_total, int kbyte0, char* tile) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    FW_MEM void issue(int step, char* tile) const {
+        const long off = (long)step * KT * kstride;
 #pragma unroll
-    for (int it = 0; it < ROWS / 32; ++it) {
-        const int R0 = (wave * (ROWS / 32) + it) * 8;
-        const int r = R0 + (lane >> 3), p = lane & 7;
-        int gr = row0 + r;
-        if (gr >= rows_total) gr = rows_total - 1;
-        glds16_asm(base + (long)gr * ld * TT<T>::SZ + kbyte0 + ((p ^ (swz(r) >> 4)) << 4), tile + R0 * LDS_ROW);
+        for (int it = 0; it < NI; ++it) glds16_asm(src[it] + off, tile + loff[it]);
     }
-}
+};
+// k-contiguous operand: the [ROWS][128 B] image of gemm_kernel (slot swizzle on the source address)
+template <typename T, int ROWS> struct GldsKc {
+    static constexpr int NI = ROWS / 32;
+    const char* src[NI];
+    int loff[NI];
+    FW_MEM void init(const char* base, long ld, int row0, int rows_total, int kbyte0) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int R0 = (wave * NI + it) * 8;
+            const int r = R0 + (lane >> 3), p = lane & 7;
+            int gr = row0 + r;
+            if (gr >= rows_total) gr = rows_total - 1;     // rows past the end only feed masked outputs
+            src[it] = base + (long)gr * ld * TT<T>::SZ + kbyte0 + ((p ^ (swz(r) >> 4)) << 4);
+            loff[it] = R0 * LDS_ROW;
+        }
+    }
+    FW_MEM void issue(int step, char* tile) const {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) glds16_asm(src[it] + (long)step * 128, tile + loff[it]);
+    }
+};
 
 template <bool XT, int KT, int NS>
 __global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
@@ -613,15 +643,15 @@ __global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     {                                                     // contiguous eighths of the (slice, n tile, m tile) order per XCD, see gemm_kernel
         const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-        if (gridDim.z > 1 && (total & 7) == 0) {
+        if (gridDim.z > 1) {
             const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            const unsigned w = xcd_contiguous(lin, total);
             bx = (int)(w % gridDim.x);
             by = (int)((w / gridDim.x) % gridDim.y);
             bz = (int)(w / (gridDim.x * gridDim.y));
-        } else if (gridDim.z == 1 && gridDim.y > 1 && (total & 7) == 0) {
+        } else if (gridDim.z == 1 && gridDim.y > 1) {
             const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            const unsigned w = xcd_contiguous(lin, total);
             const unsigned per_band = 8 * gridDim.y;
             const unsigned band = w / per_band, first = band * 8;
             const unsigned gsz = min(gridDim.x - first, 8u);
@@ -642,11 +672,16 @@ __global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
     const bool do_xsum = XT && a.xsum != nullptr && by == 0 && wn0 == 0;    // wave-uniform
     const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // bf16 1.0 x 8
 
+    GldsKm<KT> gw;
+    gw.init(a.W, a.ldw, n_blk, a.N, k_begin);
+    GldsKm<XT ? KT : 16> gxm;
+    GldsKc<T, BM> gxc;
+    if constexpr (XT) gxm.init(a.X, a.ldx, m_blk, a.M, k_begin);
+    else gxc.init(a.X, a.ldx, m_blk, a.M, k_begin * 2);
     auto issue = [&](int step, int buf) {
-        const int k0 = k_begin + step * KT;
-        if constexpr (XT) glds_issue_km_t<KT>(a.X, a.ldx, m_blk, a.M, k0, xs(buf));
-        else glds_issue_asm<T, BM>(a.X, a.ldx, m_blk, a.M, k0 * 2, xs(buf));
-        glds_issue_km_t<KT>(a.W, a.ldw, n_blk, a.N, k0, ws(buf));
+        if constexpr (XT) gxm.issue(step, xs(buf));
+        else gxc.issue(step, xs(buf));
+        gw.issue(step, ws(buf));
     };
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
@@ -740,15 +775,15 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a) {
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     {
         const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-        if (gridDim.z > 1 && (total & 7) == 0) {
+        if (gridDim.z > 1) {
             const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            const unsigned w = xcd_contiguous(lin, total);
             bx = (int)(w % gridDim.x);
             by = (int)((w / gridDim.x) % gridDim.y);
             bz = (int)(w / (gridDim.x * gridDim.y));
-        } else if (gridDim.z == 1 && gridDim.y > 1 && (total & 7) == 0) {
+        } else if (gridDim.z == 1 && gridDim.y > 1) {
             const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-            const unsigned w = (lin & 7) * (total >> 3) + (lin >> 3);
+            const unsigned w = xcd_contiguous(lin, total);
             const unsigned per_band = 8 * gridDim.y;
             const unsigned band = w / per_band, first = band * 8;
             const unsigned gsz = min(gridDim.x - first, 8u);
@@ -765,10 +800,13 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a) {
 
     f32x4 acc[4][WM];
     zero_acc(acc);
+    GldsKc<T, BM> gx;
+    GldsKc<T, BN> gw;
+    gx.init(a.X, a.ldx, m_blk, a.M, k_begin * TT<T>::SZ);
+    gw.init(a.W, a.ldw, n_blk, a.N, k_begin * TT<T>::SZ);
     auto issue = [&](int step, int buf) {
-        const int kb = (k_begin + step * KT) * TT<T>::SZ;
-        glds_issue_asm<T, BM>(a.X, a.ldx, m_blk, a.M, kb, xs(buf));
-        glds_issue_asm<T, BN>(a.W, a.ldw, n_blk, a.N, kb, ws(buf));
+        gx.issue(step, xs(buf));
+        gw.issue(step, ws(buf));
     };
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)

@@ -37,15 +37,12 @@ _SPLITK_BLOCKS = int(_os.environ.get('FW_SPLITK_BLOCKS', '512'))       # tuning 
 
 
 def pick_splitk(M, N, K, dtype):
-    """Split factor of a weight-gradient GEMM (small M x N output, long reduction K = tokens).  Rule fitted to a sweep on
-    MI355X (tools/splitk_sweep.py): about 512 blocks in flight, at least 512 reduction rows (8 K-steps) per block."""
+    """Split factor of a weight-gradient GEMM (small M x N output, long reduction K = tokens).  Rule fitted to sweeps on MI355X
+    (tools/splitk_sweep.py, tools/wgrad_probe.py): as many blocks as fit ONE round of the chip (256 CUs x 2 workgroups = 512) and
+    never more -- 528 blocks ran 77 us where 440 ran 56 (a second round for 16 stragglers) --, with at least 512 reduction rows
+    (8 K-steps) per block.  (fw_gemm deals contiguous shares of the tile order to the 8 XCDs for ANY block count.)"""
     tiles = ((M + 127) // 128) * ((N + 63) // 64 if N <= 64 else (N + 127) // 128)
     sk = max(1, min(_SPLITK_BLOCKS // max(tiles, 1), K // 512))
-    if sk > 1 and (tiles * sk) % 8:                          # fw_gemm deals contiguous eighths of the tile order to the 8 XCDs
-        for cand in (sk + 1, sk - 1, sk + 2, sk + 3):
-            if cand > 1 and (tiles * cand) % 8 == 0 and K // cand >= 256:
-                sk = cand
-                break
     while sk > 1 and sk * M * N * 4 > (256 << 20):          # keep the partial-tile slab under 256 MB
         sk //= 2
     return int(sk)

@@ -6,7 +6,7 @@ Imports the unmodified reference through ``oracle/refshim.py`` (timm stand-in, n
 inputs with DropPath neutralised and stores inputs + outputs as small ``.npz`` files
 (``numpy.load`` with ``allow_pickle=False`` reads them) plus the state-dict schema as JSON.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [unit] [model] [moco] [model256] [debug]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [unit] [model] [moco] [model256] [debug] [convnets] [vit]
 
 A fixture is data (inputs / expected outputs); no reference source text is stored.
 """
@@ -298,6 +298,109 @@ def gen_debug():
     save('debug_all3', **arrs)
 
 
+def gen_convnets():
+    """The convolutional plug-ins of the seam (BASELINE configs[0]): everything of net/encoder_ResNet.py and net/decoder_DGRN.py that
+    RUNS in the reference -- ResBlock (stride 1 and 2, train mode: batch statistics), ResNetEncoder (eval and train, standalone),
+    SFT_layer -- forward + backward.  DCN_layer.forward ends in `assert False` (deform_conv.py:64; mmcv absent), so DGM / DGB / DGG /
+    DGRN.forward cannot be executed and are NOT in any golden: their wiring is checked against the oracle's restatement only and
+    the deformable convolution by known-answer tests (parity unpinned)."""
+    from net import encoder_ResNet as RR
+    from net import decoder_DGRN as RG
+    arrs = {}
+    for tag, cin, cout, stride, hw in (('s1', 3, 64, 1, 32), ('s2', 64, 128, 2, 16)):
+        pre = f'unit_resblock_{tag}.'
+        blk = seed_module(RR.ResBlock(cin, cout, stride), pre).train()
+        x = rnd(pre + 'x', (2, cin, hw, hw)).requires_grad_(True)
+        y = blk(x)
+        w = rnd(pre + 'dy', y.shape)
+        g = grads_of(blk, (y * w).sum())
+        a = {'x': x, 'y': y, 'dy': w, 'dx': x.grad}
+        a.update({'g.' + k: v for k, v in g.items()})
+        a.update({'s.' + k: v for k, v in blk.state_dict().items() if 'running' in k})
+        save(f'unit_resblock_{tag}', **a)
+    pre = 'unit_sft.'
+    sft = seed_module(RG.SFT_layer(64, 64), pre)
+    x = rnd(pre + 'x', (2, 64, 16, 16)).requires_grad_(True)
+    it = rnd(pre + 'inter', (2, 64, 16, 16)).requires_grad_(True)
+    y = sft(x, it)
+    w = rnd(pre + 'dy', y.shape)
+    g = grads_of(sft, (y * w).sum())
+    a = {'x': x, 'inter': it, 'y': y, 'dy': w, 'dx': x.grad, 'dinter': it.grad}
+    a.update({'g.' + k: v for k, v in g.items()})
+    save('unit_sft', **a)
+    # the whole encoder, standalone (the MoCo wrapper indexes L heads on its 1-head output in train mode, moco.py:127-128)
+    set_opt(encoder_type='ResNet', decoder_type='ResNet', encoder_dim=256, batch_size=2)
+    try:
+        pre = 'E.E.encoder_q.'
+        enc = seed_module(RR.ResNetEncoder(opt), pre)
+        x = rnd('resnet.x', (2, 3, 32, 32), 0.5)
+        enc.eval()
+        with torch.no_grad():
+            fea, out, inter = enc(x)
+        a = {'x': x, 'fea_eval': fea, 'out_eval': out[0], 'inter_eval': inter}
+        enc.train()
+        fea, out, inter = enc(x)
+        w1, w2 = rnd('resnet.dout', out[0].shape), rnd('resnet.dinter', inter.shape)
+        g = grads_of(enc, (out[0] * w1).sum() + (inter * w2).sum())
+        names = sorted(g.keys())
+        a.update({'fea_train': fea, 'out_train': out[0], 'inter_train': inter, 'dout': w1, 'dinter': w2,
+                  'grad_names': np.array(names), 'grad_norms': np.array([g[n].norm().item() for n in names])})
+        a.update({'g.' + k: v for k, v in g.items() if v.numel() <= 40000})
+        a.update({'s.' + k: v for k, v in enc.state_dict().items() if 'running' in k})
+        save('model_resnet_encoder', **a)
+        net = AirNet(opt)
+        sch = json.load(open(os.path.join(HERE, 'schema.json')))
+        sch['resnet_dgrn'] = schema_of(net)
+        json.dump(sch, open(os.path.join(HERE, 'schema.json'), 'w'))
+    finally:
+        set_opt(encoder_type='Uformer', decoder_type='Uformer')
+
+
+def gen_vit():
+    """ViT encoder (BASELINE configs[4]; encoder_ViT.py:17-203) standalone at 128x128: eval (fea, out, inter), and train mode with every
+    Dropout set to p = 0 (stochastic otherwise): outputs + all parameter gradients.  Plus the one end-to-end configuration with it
+    that runs in the reference: ViT encoder + plain Uformer decoder, eval forward."""
+    from net import encoder_ViT as RV
+    set_opt(encoder_type='ViT', decoder_type='Uformer', encoder_dim=3, batch_size=2, degradation_embedding_method=['None'],
+            frequency_decompose_type='none', out_channels=3, batch_wise_decompose=False)
+    try:
+        pre = 'E.E.encoder_q.'
+        enc = seed_module(RV.ViTEncoder(opt), pre)
+        for m in enc.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        x = rnd('vit.x', (2, 3, 128, 128), 0.5)
+        enc.eval()
+        with torch.no_grad():
+            fea, out, inter = enc(x)
+        a = {'x': x, 'fea_eval': fea, 'out_eval': out[0], 'inter_eval': inter}
+        enc.train()
+        fea, out, inter = enc(x)
+        w1, w2 = rnd('vit.dout', out[0].shape), rnd('vit.dinter', inter.shape)
+        g = grads_of(enc, (out[0] * w1).sum() + (inter * w2).sum())
+        names = sorted(g.keys())
+        a.update({'fea_train': fea, 'out_train': out[0], 'inter_train': inter, 'dout': w1, 'dinter': w2,
+                  'grad_names': np.array(names), 'grad_norms': np.array([g[n].norm().item() for n in names])})
+        for n in names:
+            if g[n].numel() <= 4096 or n in ('pos_embedding',):
+                a['g.' + n] = g[n]
+        a.update({'s.' + k: v for k, v in enc.state_dict().items() if 'running' in k})
+        save('model_vit_encoder', **a)
+        net = seed_module(AirNet(opt), '')
+        for pq, pk in zip(net.E.E.encoder_q.parameters(), net.E.E.encoder_k.parameters()):
+            pk.data.copy_(pq.data)
+        sch = json.load(open(os.path.join(HERE, 'schema.json')))
+        sch['vit_uformer'] = schema_of(net)
+        json.dump(sch, open(os.path.join(HERE, 'schema.json'), 'w'))
+        clean, q, k = synth_batch(2, 128, 'model.')
+        net.eval()
+        with torch.no_grad():
+            restored = net(x_query=q, x_key=q)
+        save('model_vit_uformer', restored_eval=restored, psnr_eval=O.psnr(restored, clean))
+    finally:
+        set_opt(encoder_type='Uformer', decoder_type='Uformer', encoder_dim=256, degradation_embedding_method=['all_3_bands'])
+
+
 def gen_moco():
     """Three consecutive train-mode steps of the encoder side only (net.E), SGD lr 0.05 on the
     query encoder in between, so that EMA, queue rotation and pointer wrap are all exercised."""
@@ -343,3 +446,7 @@ if __name__ == '__main__':
             gen_model256()
         if 'debug' in what:
             gen_debug()
+        if 'convnets' in what:
+            gen_convnets()
+        if 'vit' in what:
+            gen_vit()

@@ -674,7 +674,7 @@ int dispatch(bool bwd, int D, int nkt, int lfs, const AttnArgs& a, hipStream_t s
 #define FW_ATT(DD, KK, FF)                                                                     \
     if (D == DD && nkt == KK && lfs == FF)                                                     \
         return bwd ? bwd_launch<T, DD, KK, FF>(a, st) : fwd_launch<T, DD, KK, FF>(a, st);
-    FW_ATT(56, 1, 0) FW_ATT(56, 1, 1) FW_ATT(56, 1, 2) FW_ATT(28, 1, 0) FW_ATT(28, 2, 0)
+    FW_ATT(56, 1, 0) FW_ATT(56, 1, 1) FW_ATT(56, 1, 2) FW_ATT(28, 1, 0) FW_ATT(28, 2, 0) FW_ATT(64, 1, 0)
 #undef FW_ATT
     return -1000;      // unsupported (head_dim, key tiles, lfs) combination
 }
@@ -683,7 +683,7 @@ int dispatch(bool bwd, int D, int nkt, int lfs, const AttnArgs& a, hipStream_t s
 
 extern "C" int fw_attn_lfs_table_elems() { return OFF_END; }
 
-// dtype: 0 f32 / 1 bf16.  head_dim D in {56, 28}.  nkt: key tiles of 64 (2 = inter-band, L = 3).
+// dtype: 0 f32 / 1 bf16.  head_dim D in {56, 28} (Uformer) or 64 (ViT encoder: one 64-token "window" per image, zero bias table).  nkt: key tiles of 64 (2 = inter-band, L = 3).
 // lfs: 0 none, 1 affine (all_DC / all_2_bands), 2 affine + disc filter (all_3_bands).
 extern "C" int fw_attn_fwd(int dtype, int D, int nkt, int lfs, const void* q, const void* k, const void* v, long ld,
                            void* out, long ldo, float* lse, const float* bias, const float* coef, const void* lfs_tab,

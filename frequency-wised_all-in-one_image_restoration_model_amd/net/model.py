@@ -11,22 +11,15 @@ import torch
 from torch import nn
 
 from fwair import functional as _Fn
-from fwair.modules import MoCo, UformerDecoder, UformerEncoder
+from fwair.convnets import DGRN, ResNetEncoder                  # noqa: F401  (registered names of the seam)
+from fwair.modules import MoCo, UformerDecoder, UformerEncoder  # noqa: F401
+from fwair.vit import ViTEncoder                                # noqa: F401
 
-
-def _unsupported(name, why):
-    class _Unsupported(nn.Module):
-        def __init__(self, opt):
-            raise NotImplementedError(f'{name}: {why}')
-    _Unsupported.__name__ = name
-    return _Unsupported
-
-
-# Registered names of the seam.  The ResNet / ViT variants do not run in the reference itself
-# (DCN asserts, MoCo head-count mismatch); they are listed so the failure is explicit.
-ResNetDecoder = _unsupported('ResNetDecoder', 'DGRN needs mmcv DCNv2, absent from the reference tree; scheduled after the Uformer path')
-ResNetEncoder = _unsupported('ResNetEncoder', 'not runnable in the reference (MoCo L-mismatch); scheduled after the Uformer path')
-ViTEncoder = _unsupported('ViTEncoder', 'not runnable in train mode in the reference; scheduled after the Uformer path')
+# Registered names of the seam (net/model.py:3,17,31 of the reference: `DGRN as ResNetDecoder`).  In the reference the ResNet /
+# ViT encoders fail in TRAIN mode inside MoCo (range(opt.L) heads indexed on their 1-element output, moco.py:127-128) and the DGRN
+# decoder asserts in its deformable convolution (deform_conv.py:64); here MoCo runs len(q) heads and DCNv2 is implemented
+# (parity unpinned, see fwair/convnets.py).
+ResNetDecoder = DGRN
 
 
 def _apply_dtype(opt):

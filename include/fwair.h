@@ -170,6 +170,68 @@ int fw_lfs_lambda_bwd(const float* xbar, const unsigned long long* ptab, const u
                       const long long* coef_off, const float* dcoef, const float* save, float* dxbar, int nblk, int B, int C,
                       int nb1, void* stream);
 
+/* ---- convolutional plug-ins of the seam: ResNetEncoder (net/encoder_ResNet.py:4-47), DGRN (net/decoder_DGRN.py:9-158) ----
+ * fw_conv3x3: nn.Conv2d k3 p1 (taps 0x1ff) or k1 p0 (taps 0x010: weights at the centre tap of the same panel), stride 1 | 2, as
+ * an implicit GEMM on MFMA (decoder_DGRN.py:5-6 default_conv, :37-47 SFT 1x1 convs; encoder_ResNet.py:8,11,15 ResBlock convs;
+ * deform_conv.py:31-36 conv_offset_mask on cat[x, inter] = channels [0, cin1) from x, [cin1, cin) from x2).  x, x2, res: T
+ * [B*H*W][ld] token-major; w: T [roundup(cout, 16)][9 * cin], element (co, tap, ci); out: T or f32 [B*Ho*Wo][ldo];
+ * epilogue: + bias[co], act 1 = LeakyReLU(slope), + res.  With a flipped, transposed panel it is the input gradient of a
+ * stride-1 convolution. */
+int fw_conv3x3(int dtype, const void* x, long ldx, const void* x2, long ldx2, int cin, int cin1, const void* w, const float* bias,
+               void* out, long ldo, int out_f32, const void* res, long ldr, int cout, int B, int H, int W, int stride, int taps,
+               int act, float slope, void* stream);
+/* explicit [tokens][9 * C] operand of a 3x3 p1 convolution (weight gradients; input gradients of stride-2 convolutions) */
+int fw_im2col3(int dtype, const void* x, long ldx, void* col, int B, int H, int W, int C, int stride, void* stream);
+int fw_col2im3(int dtype, const void* dcol, void* dx, long lddx, int B, int H, int W, int C, int stride, void* stream);
+/* DCNv2, net/utils/deform_conv.py:56-67 (the reference's call into mmcv is commented out and the function asserts: parity
+ * unpinned).  om: f32 [B*H*W][32] raw conv_offset_mask output, channels 2k / 2k+1 = (dy, dx) of tap k, 18 + k = mask logit.
+ * fw_dcn_im2col: col[p][k * C + c] = sigmoid(mask_k) * bilinear(x[:, c], p + p_k + offset_k) -- the operand of a plain GEMM with
+ * the [Cout][9 * Cin] weight.  fw_dcn_bwd: dx (f32, accumulated: pre-zero) and dom from d(col). */
+int fw_dcn_im2col(int dtype, const void* x, long ldx, const float* om, void* col, int B, int H, int W, int C, void* stream);
+int fw_dcn_bwd(int dtype, const void* dcol, const void* x, long ldx, const float* om, float* dx, long lddx, float* dom, int B, int H,
+               int W, int C, void* stream);
+/* nn.BatchNorm2d (+ residual add + LeakyReLU) on a token-major map, encoder_ResNet.py:9-10,12,16,20.  sums: f32 [2][C] zeroed
+ * scratch; mr: f32 [2][C] (mean, rstd) out.  Backward: on return sums[0] = d(beta), sums[1] = d(gamma); dres = dy * lrelu'(y). */
+int fw_bn_cl_fwd(int dtype, const void* x, long ldx, const float* gamma, const float* beta, float* rmean, float* rvar, long long* nbt,
+                 float* sums, float* mr, const void* res, long ldr, void* y, long ldy, long rows, int C, int training, float eps,
+                 float momentum, float slope, void* stream);
+int fw_bn_cl_bwd(int dtype, const void* dy, long ldd, const void* y, long ldy, const void* x, long ldx, const float* mr,
+                 const float* gamma, float* sums, void* dx, long lddx, void* dres, long lddr, long rows, int C, int training,
+                 float slope, void* stream);
+/* nn.LeakyReLU on T maps (decoder_DGRN.py:40,45 inside the SFT MLPs) and its backward from the OUTPUT's sign */
+int fw_lrelu_t(int dtype, const void* x, long ldx, void* y, long ldy, long rows, int C, float slope, void* stream);
+int fw_lrelu_t_bwd(int dtype, const void* dy, long ldd, const void* y, long ldy, void* dx, long lddx, long rows, int C, float slope,
+                   void* stream);
+/* DGM + the LeakyReLU DGB applies to it (decoder_DGRN.py:22-32,79,81): out = lrelu(x + dcn + x * gamma + beta); backward:
+ * dz = dout * lrelu'(out) (= d dcn = d beta), dx = dz (1 + gamma), dgamma = dz x.  Contiguous T tensors of n elements. */
+int fw_dgm_fwd(int dtype, const void* x, const void* dcn, const void* gamma, const void* beta, void* out, long n, float slope,
+               void* stream);
+int fw_dgm_bwd(int dtype, const void* dout, const void* out, const void* x, const void* gamma, void* dx, void* dz, void* dgamma,
+               long n, float slope, void* stream);
+/* nn.AdaptiveAvgPool2d(1) on a token-major map (encoder_ResNet.py:33): [B * P][C] T -> f32 [B][C] */
+int fw_gap_cl(int dtype, const void* x, long ldx, float* out, int B, int P, int C, void* stream);
+int fw_gap_cl_bwd(int dtype, const float* dgap, void* dx, long lddx, int B, int P, int C, void* stream);
+/* image planes f32 [B][Ci][H*W] <-> token-major T [B*H*W][ld] (channels Ci .. Cp-1 zero-filled) */
+int fw_nchw_to_tokens(int dtype, const float* img, void* tok, long ld, int B, int Ci, int HW, int Cp, void* stream);
+int fw_tokens_to_nchw(int dtype, const void* tok, long ld, float* img, int B, int Ci, int HW, void* stream);
+
+/* ---- ViT encoder plug-in (net/encoder_ViT.py:17-203) --------------------------------------------------------------------
+ * The transformer body runs on fw_layernorm_*, fw_gemm and fw_attn_* (head_dim 64, one 64-token window per image, zero
+ * bias table: encoder_ViT.py:76-98 without the band re-weighting); these cover the rest:
+ * fw_add_bcast: x += self.pos_embedding[:, :n] (encoder_ViT.py:187);  out[i] = x[i] + p[i % period].
+ * fw_bn_planes_*: self.norm (BatchNorm2d + LeakyReLU 0.1) and self.avg on the [B][ED][P] planes of `inter` (:170-173,194-199); both
+ *   the normalised map (returned as `inter`) and the pooled vector are materialised, the backward takes gradients of both.
+ * fw_small_linear_*: the encoder_dim x encoder_dim MLP head (:175-179; encoder_dim = 3 by default), y = lrelu(x W^T + b, slope). */
+int fw_add_bcast(const float* x, const float* p, float* out, long n, long period, void* stream);
+int fw_bn_planes_fwd(int dtype, const void* fea, const float* gamma, const float* beta, float* rmean, float* rvar, long long* nbt, float* mr,
+                     float* inter, float* gap, int B, int ED, int P, int training, float eps, float momentum, float slope, void* stream);
+int fw_bn_planes_bwd(int dtype, const void* fea, const float* inter, const float* gamma, const float* mr, const float* dinter,
+                     const float* dgap, void* dfea, float* dgamma, float* dbeta, int B, int ED, int P, int training, float slope,
+                     void* stream);
+int fw_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, float slope, void* stream);
+int fw_small_linear_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, int M, int N,
+                        int K, float slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

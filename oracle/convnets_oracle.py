@@ -6,17 +6,22 @@ Never imported by the product path; only tests/, __graft_entry__.smoke() and ben
 Functional PyTorch over a flat {state_dict key: tensor} dict, like oracle/airnet_oracle.py; backward by autograd.
 
 Parity status
-  * ResBlock, ResNetEncoder, SFT_layer, the DGRN wiring (DGM / DGB / DGG / head / body / tail) and ViTEncoder are PINNED by
-    goldens produced from the imported reference (tests/golden/make_golden.py convnets / vit).
+  * ResBlock (stride 1 / 2, train mode), ResNetEncoder (eval and train), SFT_layer and ViTEncoder (eval and train, Dropout off) are
+    PINNED by goldens produced from the imported reference (tests/golden/make_golden.py convnets / vit;
+    tests/test_oracle_convnets.py).  ViT encoder + plain Uformer decoder, the one end-to-end configuration with these plug-ins
+    that runs in the reference, is pinned by `model_vit_uformer`.
   * DCN_layer is **parity unpinned**: the reference ends in `assert False` (deform_conv.py:64) because its arithmetic lived in
-    the third-party mmcv `modulated_deform_conv2d` (version unpinned, import commented out at deform_conv.py:7,66-67), absent
-    from the tree and from this image.  `dcn_v2` below follows deform_conv.py:56-62 for the offset / mask plumbing and restates
-    the published DCNv2 definition (Zhu et al., "Deformable ConvNets v2", eq. 1, as implemented by mmcv's
-    modulated_deform_conv2d): per output pixel p and kernel tap k,
+    the third-party mmcv `modulated_deform_conv2d` (version unpinned -- the reference has no requirements file --, import and
+    call commented out at deform_conv.py:7,66-67), absent from the tree and from this image.  `dcn_v2` below follows
+    deform_conv.py:56-62 for the offset / mask plumbing and restates the published DCNv2 definition (Zhu et al., "Deformable
+    ConvNets v2: More Deformable, Better Results", eq. 1, as mmcv's modulated_deform_conv2d implements it): per output pixel
+    p and kernel tap k,
         y(p) = sum_k w_k . m_k . x(p + p_k + dp_k),     x(.) bilinear, zero outside the image,
     offset channels interleaved (dy, dx) per tap, deformable_groups = 1.  It is anchored by known-answer tests (zero offsets
-    => sigmoid(0) * conv2d; integer offsets => shifted conv2d) instead of a golden; the goldens of the DGRN wiring were
-    produced with THIS function standing in for the asserting line, so they pin everything around it and nothing inside it.
+    => sigmoid(0) * conv2d; integer offsets => shifted conv2d; an affine image is sampled exactly).
+  * Because DCN_layer asserts, DGM / DGB / DGG / DGRN.forward cannot be executed in the reference either: their wiring
+    (decoder_DGRN.py:22-32,73-84,99-110,144-158) is restated here line by line and is **parity unpinned** as an assembly; its
+    pinned ingredients are the plain convolutions, LeakyReLU and SFT_layer.
 """
 import math
 
@@ -189,3 +194,44 @@ def vit_encoder(st, p, opt, x, training, bn_update=None, depth=12, heads=12, pat
     out = F.linear(fea, st[p + 'mlp.0.weight'], st[p + 'mlp.0.bias'])
     out = F.linear(F.leaky_relu(out, 0.1), st[p + 'mlp.2.weight'], st[p + 'mlp.2.bias'])
     return fea, [out], inter
+
+
+# --------------------------------------------------------------------------------------
+# AirNet with these plug-ins (net/model.py:59-71, net/utils/moco.py:115-166)
+# --------------------------------------------------------------------------------------
+def airnet_forward(st, opt, x_query, x_key, training, decoder, update_state=True):
+    """AirNet.forward for the ResNet / ViT encoders.  The reference's MoCo indexes `range(opt.L)` heads on their 1-element output
+    list and fails (moco.py:127-128); as the build does, the contrastive loss runs over len(q) = 1 head against
+    queue[0].  decoder(st, x_query, inter) -> restored.  Train: (restored, [logits], [labels]); eval: restored."""
+    import airnet_oracle as A
+    enc = resnet_encoder if opt.encoder_type == 'ResNet' else (lambda s, p, x, t, b=None: vit_encoder(s, p, opt, x, t, b))
+    if not training:
+        _, _, inter = enc(st, 'E.E.encoder_q.', x_query, False)
+        return decoder(st, x_query, inter)
+    bn, bnk = {}, {}
+    _, q, inter = enc(st, 'E.E.encoder_q.', x_query, True, bn)
+    q = [F.normalize(t, dim=1) for t in q]
+    with torch.no_grad():
+        if update_state:
+            A.moco_momentum_update(st)
+        kst = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in st.items()}
+        _, k, _ = enc(kst, 'E.E.encoder_k.', x_key, True, bnk)
+        k = [F.normalize(t, dim=1) for t in k]
+    queue = st['E.E.queue']
+    logits, labels = [], []
+    for i in range(len(q)):
+        l_pos = torch.einsum('nc,nc->n', q[i], k[i]).unsqueeze(-1)
+        l_neg = torch.einsum('nc,ck->nk', q[i], queue[i].clone().detach())
+        logits.append(torch.cat([l_pos, l_neg], 1) / A.MOCO_T)
+        labels.append(torch.zeros(logits[i].shape[0], dtype=torch.long))
+    if update_state:
+        with torch.no_grad():
+            bsz, ptr, K = k[0].shape[0], int(st['E.E.queue_ptr']), queue.shape[2]
+            for i in range(len(q)):
+                queue[i][:, ptr:ptr + bsz] = k[i].transpose(0, 1)
+            st['E.E.queue_ptr'][0] = (ptr + bsz) % K
+            for d_ in (bn, bnk):
+                for n, (m, v) in d_.items():
+                    st[n + 'running_mean'] = st[n + 'running_mean'] * 0.9 + 0.1 * m
+                    st[n + 'running_var'] = st[n + 'running_var'] * 0.9 + 0.1 * v
+    return decoder(st, x_query, inter), logits, labels

@@ -1,0 +1,360 @@
+"""GPU parity of the convolutional / ViT plug-ins of the seam (BASELINE configs[0] and [4]):
+  * kernels of csrc/fw_conv.hip / fw_vit.hip against plain PyTorch fp32 references of the same operator;
+  * ResBlock, ResNetEncoder, SFT_layer, ViTEncoder and ViT + Uformer (eval) against goldens produced by the REAL reference;
+  * DCN_layer (asserts in the reference: parity unpinned) by known-answer tests and against the oracle's DCNv2 restatement;
+  * the whole ResNet + DGRN model (configs[0]: batch 2, 64x64 -- not runnable in the reference) against the oracle.
+Tolerances: rel-to-max (helpers.close); f32 5e-5 .. 2e-4, bf16 2e-2 .. 6e-2."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import airnet_oracle as O
+import convnets_oracle as C
+from helpers import close, load, make_opt, schema, synth_batch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+DTYPES = ['fp32', 'bf16']
+TOL = {'fp32': 5e-5, 'bf16': 2e-2}
+
+
+def set_dtype(name):
+    from fwair import functional as Fn
+    Fn.config.compute_dtype = torch.float32 if name == 'fp32' else torch.bfloat16
+    Fn.config.direct_grads = False
+    return Fn.config.compute_dtype
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def tok(x, dtype):
+    """[B, C, H, W] -> token-major [B*H*W, C] on the device in the compute dtype"""
+    B, Cc, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, Cc).contiguous().to(DEV, dtype)
+
+
+def untok(t, B, H, W):
+    return t.float().cpu().reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def q(t, dtype):
+    return t.to(dtype).float()
+
+
+# ------------------------------------------------------------------------------------------------ implicit-GEMM convolution
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('cin,cout,stride,k,H,W', [(64, 64, 1, 3, 20, 36), (64, 128, 2, 3, 18, 34), (128, 256, 2, 3, 8, 16), (64, 128, 2, 1, 16, 16),
+                                                   (64, 27, 1, 3, 9, 17), (64, 3, 1, 3, 12, 16)])
+def test_conv_implicit_gemm(dt, cin, cout, stride, k, H, W):
+    from fwair import convnets as CV
+    dtype = set_dtype(dt)
+    B = 2
+    x = q(rnd(B, cin, H, W), dtype).requires_grad_(True)
+    conv = torch.nn.Conv2d(cin, cout, k, stride, k // 2, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(q(conv.weight * 2, dtype)); conv.bias.copy_(rnd(cout, seed=3) * 0.1)
+    ref = F.leaky_relu(conv(x), 0.1)
+    mod = torch.nn.Conv2d(cin, cout, k, stride, k // 2, bias=True).to(DEV)
+    mod.load_state_dict(conv.state_dict())
+    xt = tok(x.detach(), dtype).requires_grad_(True)
+    y = CV.conv(xt, mod, (B, H, W), stride, slope=0.1)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    close(untok(y[:, :cout], B, Ho, Wo), ref, TOL[dt], 'conv + bias + lrelu')
+    dy = q(rnd(*ref.shape, seed=5), dtype)
+    ref.backward(dy)
+    y.backward(F.pad(tok(dy, dtype), (0, y.shape[1] - cout)))
+    close(untok(xt.grad, B, H, W), x.grad, TOL[dt] * 3, 'dx')
+    close(mod.weight.grad, conv.weight.grad, TOL[dt] * 3, 'dW')
+    close(mod.bias.grad, conv.bias.grad, TOL[dt] * 3, 'db')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_conv_cat_input_and_residual(dt):
+    """conv_offset_mask on cat[x, inter] (two source tensors, f32 output, 27 -> 32 padded channels) and a residual epilogue."""
+    from fwair import convnets as CV
+    dtype = set_dtype(dt)
+    B, H, W = 2, 10, 16
+    x, it = q(rnd(B, 64, H, W), dtype).requires_grad_(True), q(rnd(B, 64, H, W, seed=1), dtype).requires_grad_(True)
+    conv = torch.nn.Conv2d(128, 27, 3, 1, 1)
+    with torch.no_grad():
+        conv.weight.copy_(q(conv.weight, dtype))
+    ref = conv(torch.cat([x, it], 1))
+    mod = torch.nn.Conv2d(128, 27, 3, 1, 1).to(DEV)
+    mod.load_state_dict(conv.state_dict())
+    xt, itt = tok(x.detach(), dtype).requires_grad_(True), tok(it.detach(), dtype).requires_grad_(True)
+    y = CV.conv(xt, mod, (B, H, W), x2=itt, out_f32=True)
+    assert y.dtype == torch.float32 and y.shape[1] == 32 and float(y[:, 27:].abs().max()) == 0
+    close(untok(y[:, :27], B, H, W), ref, TOL[dt], 'offset conv on cat[x, inter]')
+    dy = rnd(*ref.shape, seed=5)
+    ref.backward(dy)
+    y.backward(F.pad(tok(dy, torch.float32), (0, 5)))
+    close(untok(xt.grad, B, H, W), x.grad, TOL[dt] * 3, 'dx')
+    close(untok(itt.grad, B, H, W), it.grad, TOL[dt] * 3, 'dinter')
+    close(mod.weight.grad, conv.weight.grad, TOL[dt] * 3, 'dW')
+    # residual epilogue: conv2(out) + x   (decoder_DGRN.py:82)
+    c2 = torch.nn.Conv2d(64, 64, 3, 1, 1)
+    m2 = torch.nn.Conv2d(64, 64, 3, 1, 1).to(DEV)
+    with torch.no_grad():
+        c2.weight.copy_(q(c2.weight, dtype))
+    m2.load_state_dict(c2.state_dict())
+    y2 = CV.conv(xt.detach(), m2, (B, H, W), res=itt.detach())
+    close(untok(y2, B, H, W), c2(x.detach()) + it.detach(), TOL[dt], 'conv + residual')
+
+
+# ------------------------------------------------------------------------------------------------ reference goldens
+def load_module(mod, prefix, g):
+    sd = mod.state_dict()
+    for k in sd:
+        if sd[k].is_floating_point():
+            sd[k] = O.seeded_tensor(prefix + k, sd[k].shape)
+    mod.load_state_dict(sd)
+    return mod.to(DEV)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('tag,cin,cout,stride', [('s1', 3, 64, 1), ('s2', 64, 128, 2)])
+def test_res_block_vs_reference(dt, tag, cin, cout, stride):
+    from fwair import convnets as CV
+    set_dtype(dt)
+    g = load(f'unit_resblock_{tag}')
+    blk = load_module(CV.ResBlock(cin, cout, stride), f'unit_resblock_{tag}.', g).train()
+    x = g['x'].to(DEV).requires_grad_(True)
+    y = blk(x)
+    close(y, g['y'], TOL[dt] * (1 if dt == 'fp32' else 2), 'y')
+    y.backward(g['dy'].to(DEV))
+    # bf16: every map between the convolutions and the batch normalisations is STORED in bf16 (8 significant bits) and BatchNorm
+    # divides by the batch deviation: a few outliers of the input gradient reach 0.1 of its maximum
+    tol = 2e-4 if dt == 'fp32' else 0.15
+    close(x.grad, g['dx'], tol, 'dx')
+    params = dict(blk.named_parameters())
+    for k, v in g.items():
+        if k.startswith('g.'):
+            close(params[k[2:]].grad, v, tol, k)
+    sd = blk.state_dict()
+    for k, v in g.items():
+        if k.startswith('s.'):
+            close(sd[k[2:]], v, 1e-4 if dt == 'fp32' else 2e-2, k)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_sft_layer_vs_reference(dt):
+    """SFT_layer (decoder_DGRN.py:35-57) through the DGM combine kernel with a zero DCN term: x + 0 + x*gamma + beta - x."""
+    from fwair import convnets as CV
+    dtype = set_dtype(dt)
+    g = load('unit_sft')
+    sft = load_module(CV.SFT_layer(64, 64), 'unit_sft.', g)
+    B, _, H, W = g['x'].shape
+    xt, it = tok(g['x'], dtype).requires_grad_(True), tok(g['inter'], dtype).requires_grad_(True)
+    gamma, beta = sft.gamma_beta(it)
+    y = CV.DgmFn.apply(xt, torch.zeros_like(xt), gamma, beta, 1.0) - xt
+    close(untok(y, B, H, W), g['y'], TOL[dt] * 4, 'y')                # bf16: gamma, beta, x and their product each rounded to 8 bits
+    y.backward(tok(g['dy'], dtype))
+    tol = 2e-4 if dt == 'fp32' else 8e-2
+    close(untok(xt.grad, B, H, W), g['dx'], tol, 'dx')
+    close(untok(it.grad, B, H, W), g['dinter'], tol, 'dinter')
+    params = dict(sft.named_parameters())
+    for k, v in g.items():
+        if k.startswith('g.'):
+            close(params[k[2:]].grad, v, tol, k)
+
+
+def seeded_net(variant, **kw):
+    from net.model import AirNet
+    from fwair import functional as Fn
+    opt = make_opt('all3', **kw)
+    net = AirNet(opt)
+    st = O.fill_state_seeded(schema(variant))
+    sd = net.state_dict()
+    assert [(k, list(v.shape)) for k, v in sd.items()] == [(k, s) for k, s, _ in schema(variant)], 'state_dict schema'
+    for k in sd:
+        if st.get(k) is not None and sd[k].is_floating_point():
+            sd[k] = st[k]
+    net.load_state_dict(sd)
+    Fn.set_droppath_override(lambda name, n, rate, device: None)
+    return net.to(DEV), opt, st
+
+
+RESNET = dict(encoder_type='ResNet', decoder_type='ResNet', encoder_dim=256, patch_size=64, degradation_embedding_method=['residual'])
+VIT = dict(encoder_type='ViT', decoder_type='Uformer', encoder_dim=3, degradation_embedding_method=['None'], out_channels=3,
+           batch_wise_decompose=False)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_resnet_encoder_vs_reference(dt):
+    g = load('model_resnet_encoder')
+    net, opt, _ = seeded_net('resnet_dgrn', compute_dtype=dt, **RESNET)
+    enc = net.E.E.encoder_q
+    x = g['x'].to(DEV)
+    enc.eval()
+    with torch.no_grad():
+        fea, out, inter = enc(x)
+    t1, t2 = (5e-5, 2e-4) if dt == 'fp32' else (3e-2, 0.15)
+    close(fea, g['fea_eval'], t1, 'fea (eval)')
+    close(out[0], g['out_eval'], t1, 'out (eval)')
+    assert inter.shape == g['inter_eval'].shape
+    close(inter.float(), g['inter_eval'], t1, 'inter (eval)')
+    enc.train()
+    fea, out, inter = enc(x)
+    close(out[0], g['out_train'], t1, 'out (train)')
+    close(inter.float(), g['inter_train'], t1, 'inter (train)')
+    ((out[0] * g['dout'].to(DEV)).sum() + (inter.float() * g['dinter'].to(DEV)).sum()).backward()
+    params = dict(enc.named_parameters())
+    names = [str(n) for n in g['grad_names']]
+    norms = torch.tensor([params[n].grad.norm().item() for n in names], dtype=torch.float64)
+    rel = (norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(float(g['grad_norms'].max()) * 1e-6)
+    print(f'ResNet encoder {dt}: grad-norm deviation max {rel.max():.2e} median {rel.median():.2e}')
+    assert rel.max() < (1e-3 if dt == 'fp32' else 0.2) and rel.median() < (1e-4 if dt == 'fp32' else 3e-2)
+    for k, v in g.items():
+        if k.startswith('g.'):
+            close(params[k[2:]].grad, v, t2, k)
+    close(enc.state_dict()['E.1.backbone.4.running_var'], g['s.E.1.backbone.4.running_var'], 1e-4 if dt == 'fp32' else 3e-2, 'running_var')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_vit_encoder_vs_reference(dt):
+    g = load('model_vit_encoder')
+    net, opt, _ = seeded_net('vit_uformer', compute_dtype=dt, **VIT)
+    enc = net.E.E.encoder_q
+    x = g['x'].to(DEV)
+    enc.eval()
+    with torch.no_grad():
+        fea, out, inter = enc(x)
+    t1, t2 = (1e-4, 5e-4) if dt == 'fp32' else (5e-2, 0.15)
+    close(fea, g['fea_eval'], t1, 'fea (eval)')
+    close(out[0], g['out_eval'], t1, 'out (eval)')
+    close(inter, g['inter_eval'], t1, 'inter (eval)')
+    enc.train()
+    fea, out, inter = enc(x)
+    close(out[0], g['out_train'], t1, 'out (train)')
+    close(inter, g['inter_train'], t1, 'inter (train)')
+    ((out[0] * g['dout'].to(DEV)).sum() + (inter * g['dinter'].to(DEV)).sum()).backward()
+    params = dict(enc.named_parameters())
+    names = [str(n) for n in g['grad_names']]
+    norms = torch.tensor([params[n].grad.norm().item() for n in names], dtype=torch.float64)
+    rel = (norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(float(g['grad_norms'].max()) * 1e-6)
+    print(f'ViT encoder {dt}: grad-norm deviation max {rel.max():.2e} median {rel.median():.2e}')
+    assert rel.max() < (2e-3 if dt == 'fp32' else 0.3) and rel.median() < (1e-4 if dt == 'fp32' else 5e-2)
+    for k, v in g.items():
+        if k.startswith('g.'):
+            close(params[k[2:]].grad, v, t2, k)
+
+
+def test_vit_uformer_eval_vs_reference():
+    """ViT encoder + plain Uformer decoder, eval forward: the one end-to-end configuration with these plug-ins that runs in the
+    reference."""
+    g = load('model_vit_uformer')
+    net, opt, _ = seeded_net('vit_uformer', **VIT)
+    clean, q_, k_ = synth_batch(2, 128, 'model.')
+    net.eval()
+    with torch.no_grad():
+        out = net(x_query=q_.to(DEV), x_key=q_.to(DEV))
+    close(out, g['restored_eval'], 1e-4, 'restored_eval')
+    assert abs(O.psnr(out.cpu(), clean) - float(g['psnr_eval'])) < 0.01
+
+
+# ------------------------------------------------------------------------------------------------ DCNv2 (parity unpinned)
+def make_dcn(dtype, cin=64, cout=64):
+    from fwair import convnets as CV
+    d = CV.DCN_layer(cin, cout, 3, padding=1, bias=False).to(DEV)
+    with torch.no_grad():
+        d.weight.copy_(q(rnd(cout, cin, 3, 3, seed=7) * 0.05, dtype))
+    return d
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_dcn_zero_offsets_is_half_a_convolution(dt):
+    dtype = set_dtype(dt)
+    d = make_dcn(dtype)                                         # conv_offset_mask zero-initialised (deform_conv.py:52-54)
+    B, H, W = 2, 9, 16
+    x, it = q(rnd(B, 64, H, W), dtype), q(rnd(B, 64, H, W, seed=1), dtype)
+    y = d.run(tok(x, dtype), tok(it, dtype), (B, H, W))
+    close(untok(y, B, H, W), 0.5 * F.conv2d(x, d.weight.detach().cpu(), padding=1), TOL[dt], 'zero offsets: sigmoid(0) * conv2d')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_dcn_integer_offsets_shift_the_taps(dt):
+    from fwair import convnets as CV
+    dtype = set_dtype(dt)
+    d = make_dcn(dtype)
+    B, H, W = 1, 10, 16
+    x = q(rnd(B, 64, H, W), dtype)
+    om = torch.zeros(B * H * W, 32)
+    om[:, 0:18:2], om[:, 1:18:2], om[:, 18:27] = 2.0, -1.0, 30.0            # (dy, dx) = (2, -1) on every tap, mask = sigmoid(30) = 1
+    y = CV.DcnFn.apply(tok(x, dtype), om.to(DEV), d.weight, (B, H, W))
+    xp = F.pad(x, (2, 1, 1, 3))
+    ref = F.conv2d(xp, d.weight.detach().cpu())[:, :, 2:2 + H, 0:W]
+    close(untok(y, B, H, W), ref, TOL[dt], 'integer offsets')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_dcn_layer_vs_oracle(dt):
+    """Random (fractional, partly out-of-image) offsets and masks: forward and every gradient against the oracle's restatement."""
+    from fwair import convnets as CV
+    dtype = set_dtype(dt)
+    d = make_dcn(dtype)
+    with torch.no_grad():
+        d.conv_offset_mask.weight.copy_(q(rnd(27, 128, 3, 3, seed=9) * 0.03, dtype))
+        d.conv_offset_mask.bias.copy_(rnd(27, seed=10) * 0.5)
+    B, H, W = 2, 12, 16
+    x, it = q(rnd(B, 64, H, W), dtype).requires_grad_(True), q(rnd(B, 64, H, W, seed=1), dtype).requires_grad_(True)
+    st = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in d.state_dict().items()}
+    ref = C.dcn_layer(st, '', x, it)
+    xt, itt = tok(x.detach(), dtype).requires_grad_(True), tok(it.detach(), dtype).requires_grad_(True)
+    y = d.run(xt, itt, (B, H, W))
+    close(untok(y, B, H, W), ref, TOL[dt] * 2, 'DCN forward')
+    dy = q(rnd(*ref.shape, seed=5), dtype)
+    ref.backward(dy)
+    y.backward(tok(dy, dtype))
+    tol = 3e-4 if dt == 'fp32' else 8e-2
+    close(untok(xt.grad, B, H, W), x.grad, tol, 'dx')
+    close(untok(itt.grad, B, H, W), it.grad, tol, 'dinter (through the offsets and masks)')
+    close(d.weight.grad, st['weight'].grad, tol, 'dW')
+    close(d.conv_offset_mask.weight.grad, st['conv_offset_mask.weight'].grad, tol, 'd conv_offset_mask.weight')
+    close(d.conv_offset_mask.bias.grad, st['conv_offset_mask.bias'].grad, tol, 'd conv_offset_mask.bias')
+
+
+# ------------------------------------------------------------------------------------------------ configs[0] end to end
+@pytest.mark.parametrize('dt', DTYPES)
+def test_resnet_dgrn_model_vs_oracle(dt):
+    """BASELINE configs[0]: ResNet encoder + DGRN decoder, batch 2, 64x64.  The reference cannot run it (DCN asserts, MoCo indexes L
+    heads): eval output and one training step (loss, logits, gradients of every kind, queue) against the oracle."""
+    net, opt, st = seeded_net('resnet_dgrn', compute_dtype=dt, **RESNET)
+    clean, q_, k_ = synth_batch(2, 64, 'cfg0.')
+    dec = lambda s, x, inter: C.dgrn(s, 'R.R.', x, inter)
+    with torch.no_grad():
+        ref_eval = C.airnet_forward(st, opt, q_, q_, False, dec)
+    net.eval()
+    with torch.no_grad():
+        out = net(x_query=q_.to(DEV), x_key=q_.to(DEV))
+    t1, t2 = (2e-4, 2e-3) if dt == 'fp32' else (5e-2, 0.3)
+    close(out, ref_eval, t1, 'restored (eval)')
+    names = [k for k in st if st[k] is not None and st[k].is_floating_point() and O.is_parameter_key(k) and not k.startswith('E.E.encoder_k.')]
+    for n in names:
+        st[n] = st[n].clone().requires_grad_(True)
+    restored, logits, labels = C.airnet_forward(st, opt, q_, k_, True, dec)
+    loss, l1, contrast = O.training_loss(opt, restored, logits, labels, clean)
+    loss.backward()
+    net.train()
+    r2, lg2, lb2 = net(x_query=q_.to(DEV), x_key=k_.to(DEV))
+    assert len(lg2) == 1 and lg2[0].shape == logits[0].shape
+    close(r2, restored, t1, 'restored (train)')
+    close(torch.stack(lg2), torch.stack(logits), t1 * 2, 'logits')
+    CE = torch.nn.CrossEntropyLoss()
+    loss2 = torch.nn.L1Loss()(r2, clean.to(DEV)) + 0.6 * CE(lg2[0], lb2[0])
+    close(loss2, loss, 1e-4 if dt == 'fp32' else 2e-2, 'loss')
+    loss2.backward()
+    params = dict(net.named_parameters())
+    gn = torch.tensor([float(st[n].grad.norm()) for n in names], dtype=torch.float64)
+    mine = torch.tensor([float(params[n].grad.norm()) for n in names], dtype=torch.float64)
+    rel = (mine - gn).abs() / gn.clamp_min(float(gn.max()) * 1e-6)
+    print(f'ResNet + DGRN {dt}: grad-norm deviation max {rel.max():.2e} median {rel.median():.2e} ({names[int(rel.argmax())]})')
+    assert rel.median() < (1e-4 if dt == 'fp32' else 5e-2) and rel.max() < (5e-3 if dt == 'fp32' else 1.0)
+    for n in ('R.R.tail.0.weight', 'R.R.head.0.weight', 'R.R.body.2.body.3.dgm1.dcn.weight', 'R.R.body.0.body.0.dgm2.dcn.conv_offset_mask.weight',
+              'R.R.body.4.body.1.dgm1.sft.conv_gamma.0.weight', 'R.R.body.1.body.5.bias', 'E.E.encoder_q.E_pre.backbone.0.weight',
+              'E.E.encoder_q.E.1.backbone.4.weight', 'E.E.encoder_q.mlp.2.weight'):
+        # gradients that are ~0 by cancellation (the encoder's: the contrastive term is ~1e-6 with these weights) only see rounding
+        close(params[n].grad, st[n].grad, t2 if float(st[n].grad.norm()) > 1e-6 * float(gn.max()) else 0.2, 'grad ' + n)
+    close(net.E.E.queue[0], st['E.E.queue'][0], 1e-4 if dt == 'fp32' else 2e-2, 'queue[0] after the step')

@@ -66,8 +66,27 @@ def test_unsupported_configurations_fail_loudly():
     from net.model import AirNet
     with pytest.raises(NotImplementedError):
         AirNet(make_opt('all3', degradation_embedding_method=['residual']))        # the CLI default does not run in the reference either
-    with pytest.raises(NotImplementedError):
-        AirNet(make_opt('all3', encoder_type='ResNet', decoder_type='ResNet'))
+    with pytest.raises(NotImplementedError):                                        # the band re-weighting `lamb` of the ViT attention
+        AirNet(make_opt('all3', encoder_type='ViT', encoder_dim=3, out_channels=3, batch_wise_decompose=False,
+                        degradation_embedding_method=['None'], frequency_decompose_type='3_bands'))
+
+
+@pytest.mark.parametrize('variant,kw', [
+    ('resnet_dgrn', dict(encoder_type='ResNet', decoder_type='ResNet', encoder_dim=256, patch_size=64, degradation_embedding_method=['residual'])),
+    ('vit_uformer', dict(encoder_type='ViT', decoder_type='Uformer', encoder_dim=3, degradation_embedding_method=['None'], out_channels=3,
+                         batch_wise_decompose=False))])
+def test_convnet_and_vit_seam_schemas_match_reference(variant, kw):
+    """BASELINE configs[0] / [4]: the ResNet / DGRN / ViT names of the seam (net/model.py:3,17,31) build, with the reference's
+    state_dict keys, shapes, dtypes and order (tests/golden/schema.json, dumped from the reference's own AirNet(opt))."""
+    from net.model import AirNet
+    net = AirNet(make_opt('all3', **kw))
+    mine = [(k, list(v.shape), str(v.dtype).replace('torch.', '')) for k, v in net.state_dict().items()]
+    assert mine == [(k, list(s), d) for k, s, d in schema(variant)]
+    for pq, pk in zip(net.E.E.encoder_q.parameters(), net.E.E.encoder_k.parameters()):
+        assert torch.equal(pq, pk) and not pk.requires_grad
+    if variant == 'resnet_dgrn':                             # deform_conv.py:52-54: offsets / masks start at zero
+        d = net.R.R.body[0].body[0].dgm1.dcn
+        assert float(d.conv_offset_mask.weight.abs().max()) == 0 and d.bias is None and tuple(d.weight.shape) == (64, 64, 3, 3)
 
 
 def test_patch_size_sets_the_model_resolution():

@@ -632,7 +632,7 @@ template <bool XT, int KT, int NS>
 __global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
     using T = bf16raw;
     static_assert(XT || KT == 64, "the k-contiguous X image is built for 64-deep steps");
-    static_assert(NS >= 3 && NS <= 5, "ring depth");
+    static_assert(NS >= 2 && NS <= 5, "ring depth");
     constexpr int WM = 4;
     constexpr int XB = XT ? KT * 256 : 128 * LDS_ROW, WB = KT * 256, STAGE = XB + WB;
     constexpr int LPS = (XT ? KT / 16 : 4) + KT / 16;          // global_load_lds instructions per thread and stage
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
         // stages s+1 .. s+NS-2 may stay in flight; near the tail fewer were issued
         const int younger = min(NS - 2, nsteps - 1 - s);
         if (younger >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
-        else if (NS >= 4 && younger == NS - 3) wait_vmcnt<(NS - 3) * LPS>();
+        else if (NS >= 4 && younger == NS - 3) wait_vmcnt<(NS >= 4 ? NS - 3 : 0) * LPS>();
         else if (NS >= 5 && younger == NS - 4) wait_vmcnt<(NS >= 5 ? NS - 4 : 0) * LPS>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -1088,7 +1088,13 @@ int dispatch_trans(const GemmArgs& a, int xt, int wt, hipStream_t st) {
     const bool gx = !xt && whole && a.x_op == 0, gw = !wt && whole && a.w_op == 0;
     if (!xt && !wt) {
         static const int ring = getenv("FW_GEMM_RING") ? atoi(getenv("FW_GEMM_RING")) : 1;        // 0: gemm_kernel (one stage in flight)
-        if (gx && gw && ring && a.kper % kt == 0) return BN == 128 ? launch_ring<T, BN, 4>(a, st) : launch_ring<T, BN, 3>(a, st);
+        if (gx && gw && ring && a.kper % kt == 0) {
+            // LDS per workgroup decides the residency: 2 stages of 128 x 128 = 64 KB -> 2 workgroups per CU (ring 1, default);
+            // deeper rings of one resident workgroup measured SLOWER (tools/probe/glds_probe.hip: 28 -> 42 us)
+            if (ring == 2) return BN == 128 ? launch_ring<T, BN, 3>(a, st) : launch_ring<T, BN, 3>(a, st);
+            if (ring == 3) return BN == 128 ? launch_ring<T, BN, 4>(a, st) : launch_ring<T, BN, 4>(a, st);
+            return launch_ring<T, BN, 2>(a, st);
+        }
         if (gx && gw) return launch<T, BN, false, false, true, true>(a, st);
         if (gx) return launch<T, BN, false, false, true, false>(a, st);
         if (gw) return launch<T, BN, false, false, false, true>(a, st);
@@ -1161,6 +1167,7 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
         if (x_trans && (use_tr & 1) && ldx % 8 == 0) {
             g_last_variant = 100011;
             if (ring == 1) return launch_tr_ring<true, 32, 4>(a, st);
+            if (ring == 5) return launch_tr_ring<true, 64, 2>(a, st);
             if (ring == 2) return launch_tr_ring<true, 64, 3>(a, st);
             if (ring == 3) return launch_tr_ring<true, 64, 4>(a, st);
             if (ring == 4) return launch_tr_ring<true, 32, 5>(a, st);
@@ -1169,6 +1176,7 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
         static const long tr_min_tiles = getenv("FW_GEMM_TR_MIN_TILES") ? atol(getenv("FW_GEMM_TR_MIN_TILES")) : 384;
         if (!x_trans && (use_tr & 2) && !xsum && (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk >= tr_min_tiles) {
             g_last_variant = 100001;
+            if (ring == 5) return launch_tr_ring<false, 64, 2>(a, st);
             if (ring == 2 || ring == 1) return launch_tr_ring<false, 64, 3>(a, st);
             if (ring == 3 || ring == 4) return launch_tr_ring<false, 64, 4>(a, st);
             return launch_tr<false>(a, st);

@@ -653,6 +653,526 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_kernel(AttnArgs a) {
 }
 
 
+// =====================================================================================================
+// v2 kernels for one key tile (decoder W-MSA + LFS, encoder intra / origin, ViT): everything a window needs beyond its own
+// Q / K / V / dO tiles lives ON CHIP, and the next window's tiles are already in flight while the current one is computed.
+//
+// The kernels above spend their time WAITING, not computing (rocprofv3: 61 % of wave cycles in s_waitcnt; 45 us per head-window
+// against 0.9 us of MFMA): per window they chain a dozen global round trips -- tile loads, the relative-position gather, eight
+// rounds of DFT-panel fragments from L2, and three stores that sit in front of the next window's loads in the in-order vmcnt
+// queue.  Here
+//   * the DFT panels are staged once per workgroup into LDS (23 KB bf16): CH / SH / GC / GSN of the v1 table are transposes of
+//     CU / SU / C2 / S2N and are read with the transposing fragment read, the negated panels are sign flips in registers; rows
+//     48..63 of the u axis alias the C2 / S2N panels behind them (finite values, multiplied by the zero padding of Y);
+//   * the 225 relative-position biases of the workgroup's (table, head) are staged once into LDS: a workgroup keeps one head
+//     and one query band for its whole life (grid = chunks x heads x bands) and walks a contiguous range of windows;
+//   * the tile loads of window t+1 are issued right after window t's tiles are committed to LDS, i.e. BEFORE window t's stores:
+//     they are older in the vmcnt queue, so waiting for them never waits for a store;
+//   * backward, bf16: the two applications of the band filter (on P and on dP') run as ONE pass over two tiles -- half the
+//     barriers, every panel fragment used twice.
+// One workgroup of 4 waves per CU (backward; LDS 111 KB) or two (forward, 77 KB): with nothing left to wait for, occupancy is not
+// what hides latency any more.
+template <typename T> struct FiltTab {
+    static constexpr int SZ = TT<T>::SZ;
+    static constexpr int LDP = 64 * SZ + 16;
+    static constexpr int OFF_CU = 0, OFF_C2 = 48 * LDP, OFF_SU = 80 * LDP, OFF_S2N = 128 * LDP, OFF_MW = 160 * LDP;
+    static constexpr int BYTES = OFF_MW + NU * NV * 4;
+};
+template <typename T> FW_DEV void stage_filter_tables(char* lds, const char* lfs) {
+    using F = FiltTab<T>;
+    constexpr int SZ = F::SZ, GR = 64 * SZ / 16;                       // 16-byte granules per 64-element row
+    for (int idx = threadIdx.x; idx < 160 * GR; idx += NTH) {
+        const int r = idx / GR, g = idx % GR;
+        const int src = r < 48 ? OFF_CU + r * 64 : r < 80 ? OFF_C2 + (r - 48) * 64 : r < 128 ? OFF_SU + (r - 80) * 64 : OFF_S2N + (r - 128) * 64;
+        *reinterpret_cast<uint4*>(lds + r * F::LDP + g * 16) = *reinterpret_cast<const uint4*>(lfs + (size_t)src * SZ + g * 16);
+    }
+    const char* mw = lfs + (size_t)OFF_END * SZ;
+    for (int idx = threadIdx.x; idx < NU * NV / 4; idx += NTH)
+        *reinterpret_cast<uint4*>(lds + F::OFF_MW + idx * 16) = *reinterpret_cast<const uint4*>(mw + idx * 16);
+}
+template <typename T> FW_DEV uint4 frag_neg(const uint4& v) {
+    constexpr unsigned m = sizeof(T) == 2 ? 0x80008000u : 0x80000000u;
+    return make_uint4(v.x ^ m, v.y ^ m, v.z ^ m, v.w ^ m);
+}
+// B1 on NT tiles at once.  in[t][jt] / out[t][jt] as in band_filter; scrA[t], scrB[t]: per-tile scratch pairs (>= 64*LDP and
+// >= max(64*LDP, 2*64*LDV) bytes) free on entry and on return; tab: the LDS image of stage_filter_tables.
+template <typename T, int NT>
+FW_DEV void band_filter2(const f32x4 (&in)[NT][4], f32x4 (&out)[NT][4], char* const (&scrA)[NT], char* const (&scrB)[NT], const char* tab) {
+    using G = Geo<T, 56>;
+    using F = FiltTab<T>;
+    constexpr int SZ = G::SZ, LDP = G::LDP, LDV = G::LDV, JC = G::JC, VC = G::VC;
+    const float* Mw = reinterpret_cast<const float*>(tab + F::OFF_MW);
+    const int l = lane_id(), w = wave_id();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) store_acc_T<T>(scrA[t], LDP, jt * 16, w * 16, in[t][jt]);
+    wave_fence();
+    {   // T[i][v] = sum_j P[i][j] Fv[j][v]: rows i of the own strip; stored transposed -> [v][i]
+        f32x4 tr[NT][2], ti[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { tr[t][n] = f32x4{0.f, 0.f, 0.f, 0.f}; ti[t][n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < JC; ++c) {
+            uint4 av[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) av[t] = frag_kc(scrA[t], LDP, w * 16, c);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const uint4 bc = frag_kc(tab + F::OFF_C2, LDP, n * 16, c), bs = frag_kc(tab + F::OFF_S2N, LDP, n * 16, c);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { mma_chunk<T>(tr[t][n], av[t], bc); mma_chunk<T>(ti[t][n], av[t], bs); }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                store_acc_T<T>(scrB[t], LDP, w * 16, n * 16, tr[t][n]);
+                store_acc_T<T>(scrB[t] + 32 * LDP, LDP, w * 16, n * 16, ti[t][n]);
+            }
+    }
+    __syncthreads();
+    if (w < 3) {   // X = Fu T, Y = Mw * X -> [v][u]; waves 0..2 own a 16-row tile of u each, wave 3 clears the k padding u = 48..63
+        f32x4 xr[NT][2], xi[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { xr[t][n] = f32x4{0.f, 0.f, 0.f, 0.f}; xi[t][n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < JC; ++c) {
+            const uint4 ac = frag_kc(tab + F::OFF_CU, LDP, w * 16, c), as = frag_kc(tab + F::OFF_SU, LDP, w * 16, c);
+            const uint4 an = frag_neg<T>(as);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const uint4 br = frag_kc(scrB[t], LDP, n * 16, c), bi = frag_kc(scrB[t] + 32 * LDP, LDP, n * 16, c);
+                    mma_chunk<T>(xr[t][n], ac, br); mma_chunk<T>(xr[t][n], as, bi);
+                    mma_chunk<T>(xi[t][n], ac, bi); mma_chunk<T>(xi[t][n], an, br);
+                }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f32x4 wt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wt[r] = Mw[(w * 16 + ((l >> 4) << 2) + r) * NV + n * 16 + (l & 15)];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                store_acc_T<T>(scrA[t], LDP, w * 16, n * 16, xr[t][n] * wt);
+                store_acc_T<T>(scrA[t] + 32 * LDP, LDP, w * 16, n * 16, xi[t][n] * wt);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            for (int idx = l; idx < 64 * 4; idx += 64) {
+                const int row = idx >> 2, part = idx & 3;
+                char* p = scrA[t] + row * LDP + 48 * SZ + part * 4 * SZ;
+                if (SZ == 4) *reinterpret_cast<uint4*>(p) = make_uint4(0, 0, 0, 0); else *reinterpret_cast<uint2*>(p) = make_uint2(0, 0);
+            }
+    }
+    __syncthreads();
+    {   // Z^T[v][i] = sum_u Y^T[v][u] FuH[i][u] (own columns i); FuH = transposed CU / SU panels; stored transposed -> [i][v]
+        f32x4 zr[NT][2], zi[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { zr[t][m] = f32x4{0.f, 0.f, 0.f, 0.f}; zi[t][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < JC; ++c) {
+            const uint4 bc = frag_km<T>(tab + F::OFF_CU, LDP, w * 16, c), bs = frag_km<T>(tab + F::OFF_SU, LDP, w * 16, c);
+            const uint4 bn = frag_neg<T>(bs);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const uint4 ar = frag_kc(scrA[t], LDP, m * 16, c), ai = frag_kc(scrA[t] + 32 * LDP, LDP, m * 16, c);
+                    mma_chunk<T>(zr[t][m], ar, bc); mma_chunk<T>(zr[t][m], ai, bn);
+                    mma_chunk<T>(zi[t][m], ai, bc); mma_chunk<T>(zi[t][m], ar, bs);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                store_acc_T<T>(scrB[t], LDV, m * 16, w * 16, zr[t][m]);
+                store_acc_T<T>(scrB[t] + 64 * LDV, LDV, m * 16, w * 16, zi[t][m]);
+            }
+    }
+    wave_fence();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) out[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < VC; ++c) {   // out^T[j][i] = sum_v G[j][v] Z[i][v]; G = transposed C2 / S2N panels
+        uint4 ac[4], as[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { ac[m] = frag_km<T>(tab + F::OFF_C2, LDP, m * 16, c); as[m] = frag_km<T>(tab + F::OFF_S2N, LDP, m * 16, c); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint4 br = frag_kc(scrB[t], LDV, w * 16, c), bi = frag_kc(scrB[t] + 64 * LDV, LDV, w * 16, c);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { mma_chunk<T>(out[t][m], ac[m], br); mma_chunk<T>(out[t][m], as[m], bi); }
+        }
+    }
+    __syncthreads();
+}
+
+// bias + shift mask with the 225 biases of (table, head) in LDS
+FW_DEV float bias_mask_lds(const float* bins, int i, int j, int shift, bool last_y, bool last_x) {
+    float b = bins[((i >> 3) - (j >> 3) + 7) * 15 + (i & 7) - (j & 7) + 7];
+    if (shift > 0) {
+        const int s = 8 - shift;
+        const int ri = (last_y ? ((i >> 3) < s ? 1 : 2) : 0) * 3 + (last_x ? ((i & 7) < s ? 1 : 2) : 0);
+        const int rj = (last_y ? ((j >> 3) < s ? 1 : 2) : 0) * 3 + (last_x ? ((j & 7) < s ? 1 : 2) : 0);
+        if (ri != rj) b += -100.0f;
+    }
+    return b;
+}
+
+template <typename T, int D, int LFS> struct Smem2 {
+    using G = Geo<T, D>;
+    static constexpr int TAB = LFS == 2 ? FiltTab<T>::BYTES : 0;
+    static constexpr int SCR = 2 * 64 * G::LDV > 64 * G::LDP ? 2 * 64 * G::LDV : 64 * G::LDP;
+    static constexpr int NTF = (LFS == 2 && sizeof(T) == 2) ? 2 : 1;                 // tiles per backward filter pass
+    static constexpr int OFF_BIAS = TAB;
+    static constexpr int OFF_T = TAB + 1024;                                          // tiles start here
+    static constexpr int RA = SCR > G::TILE_D ? SCR : G::TILE_D;                      // fwd: Q -> P' / scratch A
+    static constexpr int FWD_BYTES = OFF_T + RA + RA + G::TILE_D;                     // | A | B (K, scratch B, O staging) | V
+    static constexpr int BWD_BYTES = OFF_T + 4 * G::TILE_D + 2 * NTF * SCR;           // Q dO K V | (X, Y) per filter tile
+};
+
+template <typename T, int D, int LFS>
+__global__ __launch_bounds__(NTH, 1) void attn2_fwd_kernel(AttnArgs a) {
+    using G = Geo<T, D>;
+    using S = Smem2<T, D, LFS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const char* tab = smem;
+    float* bins = reinterpret_cast<float*>(smem + S::OFF_BIAS);
+    char* rA = smem + S::OFF_T; char* rB = rA + S::RA; char* rV = rB + S::RA;
+    const int l = lane_id(), w = wave_id();
+    const int nWx = a.W / 8, nWy = a.H / 8, nW = nWx * nWy;
+    const int h = blockIdx.y, lq = blockIdx.z;
+    const int i = w * 16 + (l & 15);
+    const int per = (a.nwin + gridDim.x - 1) / gridDim.x;
+    const int win_begin = blockIdx.x * per, win_end = min(a.nwin, win_begin + per);
+    if (win_begin >= win_end) return;
+    if constexpr (LFS == 2) stage_filter_tables<T>(smem, a.lfs);
+    {
+        const float* tb = a.bias + (size_t)(lq * a.L + lq) * 225 * a.heads + h;
+        for (int idx = threadIdx.x; idx < 225; idx += NTH) bins[idx] = tb[(size_t)idx * a.heads];
+    }
+    TileLoad<T, D> tq, tk, tv;
+    auto issue = [&](int win) {
+        const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
+        const int nq = lq * a.B + b;
+        tq.issue(a.q, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
+        tk.issue(a.k, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
+        tv.issue(a.v, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
+    };
+    issue(win_begin);
+    for (int win = win_begin; win < win_end; ++win) {
+        const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
+        const bool last_y = wy == nWy - 1, last_x = wx == nWx - 1;
+        const int nq = lq * a.B + b;
+        const size_t item = ((size_t)win * a.L + lq) * a.heads + h;
+        __syncthreads();                    // the previous window's readers are done (also: tables / biases are staged)
+        tq.commit(rA); tk.commit(rB); tv.commit(rV);
+        __syncthreads();
+        if (win + 1 < win_end) issue(win + 1);      // in flight during this window's compute, older than its stores
+        f32x4 p[1][4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) p[0][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < G::KC; ++c) {
+            const uint4 bq = frag_kc(rA, G::LDR, w * 16, c);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) mma_chunk<T>(p[0][m], frag_kc(rB, G::LDR, m * 16, c), bq);
+        }
+        {
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jt * 16 + ((l >> 4) << 2) + r;
+                    const float sc = p[0][jt][r] * a.scale + bias_mask_lds(bins, i, j, a.shift, last_y, last_x);
+                    p[0][jt][r] = sc;
+                    mx = fmaxf(mx, sc);
+                }
+            mx = col_reduce_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = __expf(p[0][jt][r] - mx); p[0][jt][r] = e; sum += e; }
+            sum = col_reduce_sum(sum);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) p[0][jt] *= inv;
+            if ((l >> 4) == 0) a.lse[item * 64 + i] = mx + __logf(sum);
+        }
+        __syncthreads();                    // Q / K tiles are dead from here on
+        if constexpr (LFS >= 1) {
+            const float* cf = a.coef + ((size_t)b * a.heads + h) * 3;
+            const float ca = cf[0], cb = cf[1], cc = cf[2];
+            if constexpr (LFS == 2) {
+                f32x4 f1[1][4];
+                char* const sa[1] = {rA}; char* const sb[1] = {rB};
+                band_filter2<T, 1>(p, f1, sa, sb, tab);
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) p[0][jt] = p[0][jt] * ca + cb + f1[0][jt] * cc;
+            } else {
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) p[0][jt] = p[0][jt] * ca + cb;
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) store_acc_T<T>(rA, G::LDP, jt * 16, w * 16, p[0][jt]);
+        wave_fence();
+        f32x4 o[G::DT];
+#pragma unroll
+        for (int m = 0; m < G::DT; ++m) o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < G::JC; ++c) {
+            const uint4 bp = frag_kc(rA, G::LDP, w * 16, c);
+#pragma unroll
+            for (int m = 0; m < G::DT; ++m) mma_chunk<T>(o[m], frag_km<T>(rV, G::LDR, m * 16, c), bp);
+        }
+#pragma unroll
+        for (int m = 0; m < G::DT; ++m) store_acc_T<T>(rB, G::LDR, m * 16, w * 16, o[m]);
+        wave_fence();
+        store_rows16<T, D>(rB, a.out, a.ldo, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+    }
+}
+
+template <typename T, int D, int LFS>
+__global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
+    using G = Geo<T, D>;
+    using S = Smem2<T, D, LFS>;
+    constexpr int NTF = S::NTF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const char* tab = smem;
+    float* bins = reinterpret_cast<float*>(smem + S::OFF_BIAS);
+    char* sQ = smem + S::OFF_T; char* sDO = sQ + G::TILE_D; char* sK = sDO + G::TILE_D; char* sV = sK + G::TILE_D;
+    char* sX = sV + G::TILE_D; char* sY = sX + S::SCR;
+    char* sX2 = NTF == 2 ? sY + S::SCR : sX; char* sY2 = NTF == 2 ? sX2 + S::SCR : sY;
+    const int l = lane_id(), w = wave_id();
+    const int nWx = a.W / 8, nWy = a.H / 8, nW = nWx * nWy;
+    const int h = blockIdx.y, lq = blockIdx.z;
+    const int i = w * 16 + (l & 15);
+    const int per = (a.nwin + gridDim.x - 1) / gridDim.x;
+    const int win_begin = blockIdx.x * per, win_end = min(a.nwin, win_begin + per);
+    if (win_begin >= win_end) return;
+    if constexpr (LFS == 2) stage_filter_tables<T>(smem, a.lfs);
+    {
+        const float* tb = a.bias + (size_t)(lq * a.L + lq) * 225 * a.heads + h;
+        for (int idx = threadIdx.x; idx < 225; idx += NTH) bins[idx] = tb[(size_t)idx * a.heads];
+    }
+    f32x4 dbacc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) dbacc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
+    int cs_b = -1;
+    auto flush_coef = [&]() {
+        if constexpr (LFS >= 1) {
+            if (cs_b >= 0) {
+                const float t1 = wave_sum(cs1), t2 = wave_sum(cs2), t3 = wave_sum(cs3);
+                if (l == 0) {
+                    float* dc = a.dcoef + ((size_t)cs_b * a.heads + h) * 3;
+                    atomicAdd(dc, t1); atomicAdd(dc + 1, t2);
+                    if (LFS == 2) atomicAdd(dc + 2, t3);
+                }
+            }
+            cs1 = cs2 = cs3 = 0.f;
+        }
+    };
+    TileLoad<T, D> tq, tdo, tk, tv;
+    auto issue = [&](int win) {
+        const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
+        const int nq = lq * a.B + b;
+        tq.issue(a.q, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
+        tdo.issue(a.dout, a.lddo, nq, wy, wx, a.H, a.W, a.shift, h * D);
+        tk.issue(a.k, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
+        tv.issue(a.v, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
+    };
+    issue(win_begin);
+    float lse_next = a.lse[(((size_t)win_begin * a.L + lq) * a.heads + h) * 64 + i];
+    for (int win = win_begin; win < win_end; ++win) {
+        const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
+        const bool last_y = wy == nWy - 1, last_x = wx == nWx - 1;
+        const int nq = lq * a.B + b;
+        if (b != cs_b) { flush_coef(); cs_b = b; }
+        const float lse = lse_next;
+        __syncthreads();                    // every wave is past its last read of the previous window's tiles / scratch
+        tq.commit(sQ); tdo.commit(sDO); tk.commit(sK); tv.commit(sV);
+        __syncthreads();
+        if (win + 1 < win_end) {
+            issue(win + 1);
+            lse_next = a.lse[(((size_t)(win + 1) * a.L + lq) * a.heads + h) * 64 + i];
+        }
+        // P^T[j][i] = exp(scale K Q^T + bias + mask - lse_i), dP'^T[j][i] = V dO^T  -- own columns i; both need only the tiles
+        f32x4 pd[2][4];                      // [0] = P, [1] = dP'
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) { pd[0][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; pd[1][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < G::KC; ++c) {
+            const uint4 bq = frag_kc(sQ, G::LDR, w * 16, c), bd = frag_kc(sDO, G::LDR, w * 16, c);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                mma_chunk<T>(pd[0][m], frag_kc(sK, G::LDR, m * 16, c), bq);
+                mma_chunk<T>(pd[1][m], frag_kc(sV, G::LDR, m * 16, c), bd);
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + ((l >> 4) << 2) + r;
+                pd[0][jt][r] = __expf(pd[0][jt][r] * a.scale + bias_mask_lds(bins, i, j, a.shift, last_y, last_x) - lse);
+            }
+        float ca = 1.f, cb = 0.f, cc = 0.f;
+        f32x4 fg[2][4];                      // [0] = B1(P), [1] = B1(dP')
+        if constexpr (LFS >= 1) {
+            const float* cf = a.coef + ((size_t)b * a.heads + h) * 3;
+            ca = cf[0]; cb = cf[1]; cc = cf[2];
+        }
+        if constexpr (LFS == 2) {
+            if constexpr (NTF == 2) {
+                char* const sa[2] = {sX, sX2}; char* const sb[2] = {sY, sY2};
+                band_filter2<T, 2>(pd, fg, sa, sb, tab);
+            } else {
+                char* const sa[1] = {sX}; char* const sb[1] = {sY};
+                f32x4 t0[1][4], t1[1][4];
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) t0[0][jt] = pd[0][jt];
+                band_filter2<T, 1>(t0, t1, sa, sb, tab);
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) { fg[0][jt] = t1[0][jt]; t0[0][jt] = pd[1][jt]; }
+                band_filter2<T, 1>(t0, t1, sa, sb, tab);
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) fg[1][jt] = t1[0][jt];
+            }
+        }
+        // P' = a P + b (+ c B1(P)) -> sX rows i of the own strip
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 pp = pd[0][jt] * ca + cb;
+            if constexpr (LFS == 2) pp += fg[0][jt] * cc;
+            store_acc_T<T>(sX, G::LDP, jt * 16, w * 16, LFS >= 1 ? pp : pd[0][jt]);
+        }
+        __syncthreads();
+        {   // dV^T[d][j] = sum_i dO[i][d] P'[i][j], own columns j
+            f32x4 dv[G::DT];
+#pragma unroll
+            for (int m = 0; m < G::DT; ++m) dv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < G::JC; ++c) {
+                const uint4 bn = frag_km<T>(sX, G::LDP, w * 16, c);
+#pragma unroll
+                for (int m = 0; m < G::DT; ++m) mma_chunk<T>(dv[m], frag_km<T>(sDO, G::LDR, m * 16, c), bn);
+            }
+#pragma unroll
+            for (int m = 0; m < G::DT; ++m) store_acc_T<T>(sY, G::LDR, m * 16, w * 16, dv[m]);
+            wave_fence();
+            store_rows16<T, D>(sY, a.dv, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+        }
+        // d(a, b, c) = (<dP', P>, sum dP', <B1(dP'), P>);  dP = a dP' + c B1(dP');  D_i;  dS = P o (dP - D_i)
+        {
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f, sd = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float dpv = pd[1][jt][r];
+                    if constexpr (LFS >= 1) {
+                        s1 += dpv * pd[0][jt][r]; s2 += dpv;
+                        if constexpr (LFS == 2) { s3 += fg[1][jt][r] * pd[0][jt][r]; dpv = dpv * ca + fg[1][jt][r] * cc; }
+                        else dpv *= ca;
+                    }
+                    pd[1][jt][r] = dpv;
+                    sd += pd[0][jt][r] * dpv;
+                }
+            cs1 += s1; cs2 += s2; cs3 += s3;
+            const float di = col_reduce_sum(sd);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pd[1][jt][r] = pd[0][jt][r] * (pd[1][jt][r] - di);
+                dbacc[jt] += pd[1][jt];
+            }
+        }
+        __syncthreads();                    // every wave is done reading P' (sX) and its dV staging rows (sY)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) store_acc_T<T>(sX, G::LDP, jt * 16, w * 16, pd[1][jt]);
+        __syncthreads();
+        // dQ^T[d][i] = sum_j K[j][d] dS[i][j] (own i);  dK^T[d][j] = sum_i Q[i][d] dS[i][j] (own j)
+        f32x4 dq[G::DT], dk[G::DT];
+#pragma unroll
+        for (int m = 0; m < G::DT; ++m) { dq[m] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < G::JC; ++c) {
+            const uint4 bx = frag_kc(sX, G::LDP, w * 16, c), by = frag_km<T>(sX, G::LDP, w * 16, c);
+#pragma unroll
+            for (int m = 0; m < G::DT; ++m) {
+                mma_chunk<T>(dq[m], frag_km<T>(sK, G::LDR, m * 16, c), bx);
+                mma_chunk<T>(dk[m], frag_km<T>(sQ, G::LDR, m * 16, c), by);
+            }
+        }
+        // own rows only: dK -> sY (rows j), dQ -> sV (rows i; V is dead since dP' was formed) -- no barrier between the two stores
+#pragma unroll
+        for (int m = 0; m < G::DT; ++m) {
+            store_acc_T<T>(sY, G::LDR, m * 16, w * 16, dk[m] * a.scale);
+            store_acc_T<T>(sV, G::LDR, m * 16, w * 16, dq[m] * a.scale);
+        }
+        wave_fence();
+        store_rows16<T, D>(sY, a.dk, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+        store_rows16<T, D>(sV, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+    }
+    flush_coef();
+    __syncthreads();
+    float* fold = reinterpret_cast<float*>(smem + S::OFF_T);          // tiles are dead: fold the (i, j) pairs into the 225 relative positions
+    for (int idx = threadIdx.x; idx < 225; idx += NTH) fold[idx] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = jt * 16 + ((l >> 4) << 2) + r;
+            atomicAdd(&fold[((i >> 3) - (j >> 3) + 7) * 15 + (i & 7) - (j & 7) + 7], dbacc[jt][r]);
+        }
+    __syncthreads();
+    float* dst = a.dbias + (size_t)(lq * a.L + lq) * 225 * a.heads;
+    for (int idx = threadIdx.x; idx < 225; idx += NTH) atomicAdd(dst + idx * a.heads + h, fold[idx]);
+}
+
+template <typename T, int D, int LFS>
+int fwd2_launch(const AttnArgs& a, hipStream_t st) {
+    using S = Smem2<T, D, LFS>;
+    FW_SET_LDS_ONCE((attn2_fwd_kernel<T, D, LFS>), S::FWD_BYTES);
+    const int per_cu = 2 * S::FWD_BYTES <= 160 * 1024 ? 2 : 1;
+    int chunks = (256 * per_cu) / (a.heads * a.L);
+    if (chunks < 1) chunks = 1;
+    if (chunks > a.nwin) chunks = a.nwin;
+    hipLaunchKernelGGL((attn2_fwd_kernel<T, D, LFS>), dim3(chunks, a.heads, a.L), dim3(NTH), S::FWD_BYTES, st, a);
+    FW_LAUNCH_RET();
+}
+template <typename T, int D, int LFS>
+int bwd2_launch(const AttnArgs& a, hipStream_t st) {
+    using S = Smem2<T, D, LFS>;
+    FW_SET_LDS_ONCE((attn2_bwd_kernel<T, D, LFS>), S::BWD_BYTES);
+    const int per_cu = 2 * S::BWD_BYTES <= 160 * 1024 ? 2 : 1;
+    int chunks = (256 * per_cu) / (a.heads * a.L);
+    if (chunks < 1) chunks = 1;
+    if (chunks > a.nwin) chunks = a.nwin;
+    hipLaunchKernelGGL((attn2_bwd_kernel<T, D, LFS>), dim3(chunks, a.heads, a.L), dim3(NTH), S::BWD_BYTES, st, a);
+    FW_LAUNCH_RET();
+}
+
 template <typename T, int D, int NKT, int LFS>
 int fwd_launch(const AttnArgs& a, hipStream_t st) {
     using S = Smem<T, D, NKT, LFS>;
@@ -671,6 +1191,12 @@ int bwd_launch(const AttnArgs& a, hipStream_t st) {
 
 template <typename T>
 int dispatch(bool bwd, int D, int nkt, int lfs, const AttnArgs& a, hipStream_t st) {
+    static const int v2 = getenv("FW_ATTN_V2") ? atoi(getenv("FW_ATTN_V2")) : 1;              // 0: the v1 kernels for one key tile too
+#define FW_ATT2(DD, FF)                                                                        \
+    if (v2 && D == DD && nkt == 1 && lfs == FF)                                                \
+        return bwd ? bwd2_launch<T, DD, FF>(a, st) : fwd2_launch<T, DD, FF>(a, st);
+    FW_ATT2(56, 0) FW_ATT2(56, 1) FW_ATT2(56, 2) FW_ATT2(28, 0) FW_ATT2(64, 0)
+#undef FW_ATT2
 #define FW_ATT(DD, KK, FF)                                                                     \
     if (D == DD && nkt == KK && lfs == FF)                                                     \
         return bwd ? bwd_launch<T, DD, KK, FF>(a, st) : fwd_launch<T, DD, KK, FF>(a, st);

@@ -81,9 +81,11 @@ def test_engine_step_fp32_matches_reference_golden(graph):
         rel = (norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(floor)
         # the lambda heads (attn.mlp_head / attn.mlp, norms 1e-9 .. 1e-6) hang off ONE scalar per (block, band, head) that sums 64x64
         # cancelling terms over every window: they move by ~1e-3 with the order of the float atomics; everything else is judged 10x tighter
-        lam = torch.tensor(['.attn.mlp' in n for n in names])
+        # ... as are the query encoder's: its only loss is the contrastive term, ~6e-6 with the seeded weights, so ALL its gradients are
+        # ~1e-7 (1e-6 of the largest norm) and carry the f32 rounding of a log-sum-exp that is 1 + 1e-6
+        lam = torch.tensor(['.attn.mlp' in n or n.startswith('E.E.') for n in names])
         worst, worst_o = int(rel.argmax()), int((rel * ~lam).argmax())
-        print(f'engine(graph={graph}) fp32: loss err {e_loss:.2e}; grad-norm deviation: lambda heads max {rel[lam].max():.2e} ({names[worst]}), '
+        print(f'engine(graph={graph}) fp32: loss err {e_loss:.2e}; grad-norm deviation: lambda heads / encoder max {rel[lam].max():.2e} ({names[worst]}), '
               f'all other parameters max {rel[~lam].max():.2e} ({names[worst_o]}), median {rel.median():.2e}')
         assert rel[lam].max() < 5e-3, f'grad norm of {names[worst]}: {norms[worst]:.6e} vs {g["grad_norms"][worst]:.6e}'
         assert rel[~lam].max() < 5e-4, f'grad norm of {names[worst_o]}: {norms[worst_o]:.6e} vs {g["grad_norms"][worst_o]:.6e}'

@@ -110,6 +110,15 @@ FW_DEV void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier for LDS traffic ONLY.  `__syncthreads()` also drains the vector-memory queue (s_waitcnt vmcnt(0)): it would
+// wait for the tiles being prefetched for the NEXT window and for the acknowledgements of the stores just issued -- three exposed
+// global round trips per window in the v2 kernels.  LDS consistency needs the DS queue drained and the barrier, nothing more.
+FW_DEV void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // Copy the 64 window rows of one head ([64][D]) global -> LDS tile (zero padded to whole chunks); whole workgroup.
 // Two phases: issue() only loads (clamped coordinates, no lane-varying branch, nothing consumes the data), commit() zero-pads
 // and writes LDS -- so the loads of SEVERAL tiles (Q, K, V, dO) are in flight together instead of one memory latency each.
@@ -676,9 +685,10 @@ template <typename T> struct FiltTab {
     static constexpr int SZ = TT<T>::SZ;
     static constexpr int LDP = 64 * SZ + 16;
     static constexpr int OFF_CU = 0, OFF_C2 = 48 * LDP, OFF_SU = 80 * LDP, OFF_S2N = 128 * LDP, OFF_MW = 160 * LDP;
-    static constexpr int BYTES = OFF_MW + NU * NV * 4;
+    static constexpr int BYTES = OFF_MW + NU * NV * 4;      // with the mask weights on chip
+    static constexpr int BYTES_NOMW = OFF_MW;                // mask weights read from global (L1-resident, 8 values per lane and window)
 };
-template <typename T> FW_DEV void stage_filter_tables(char* lds, const char* lfs) {
+template <typename T, bool MW> FW_DEV void stage_filter_tables(char* lds, const char* lfs) {
     using F = FiltTab<T>;
     constexpr int SZ = F::SZ, GR = 64 * SZ / 16;                       // 16-byte granules per 64-element row
     for (int idx = threadIdx.x; idx < 160 * GR; idx += NTH) {
@@ -686,9 +696,11 @@ template <typename T> FW_DEV void stage_filter_tables(char* lds, const char* lfs
         const int src = r < 48 ? OFF_CU + r * 64 : r < 80 ? OFF_C2 + (r - 48) * 64 : r < 128 ? OFF_SU + (r - 80) * 64 : OFF_S2N + (r - 128) * 64;
         *reinterpret_cast<uint4*>(lds + r * F::LDP + g * 16) = *reinterpret_cast<const uint4*>(lfs + (size_t)src * SZ + g * 16);
     }
-    const char* mw = lfs + (size_t)OFF_END * SZ;
-    for (int idx = threadIdx.x; idx < NU * NV / 4; idx += NTH)
-        *reinterpret_cast<uint4*>(lds + F::OFF_MW + idx * 16) = *reinterpret_cast<const uint4*>(mw + idx * 16);
+    if constexpr (MW) {
+        const char* mw = lfs + (size_t)OFF_END * SZ;
+        for (int idx = threadIdx.x; idx < NU * NV / 4; idx += NTH)
+            *reinterpret_cast<uint4*>(lds + F::OFF_MW + idx * 16) = *reinterpret_cast<const uint4*>(mw + idx * 16);
+    }
 }
 template <typename T> FW_DEV uint4 frag_neg(const uint4& v) {
     constexpr unsigned m = sizeof(T) == 2 ? 0x80008000u : 0x80000000u;
@@ -697,11 +709,11 @@ template <typename T> FW_DEV uint4 frag_neg(const uint4& v) {
 // B1 on NT tiles at once.  in[t][jt] / out[t][jt] as in band_filter; scrA[t], scrB[t]: per-tile scratch pairs (>= 64*LDP and
 // >= max(64*LDP, 2*64*LDV) bytes) free on entry and on return; tab: the LDS image of stage_filter_tables.
 template <typename T, int NT>
-FW_DEV void band_filter2(const f32x4 (&in)[NT][4], f32x4 (&out)[NT][4], char* const (&scrA)[NT], char* const (&scrB)[NT], const char* tab) {
+FW_DEV void band_filter2(const f32x4 (&in)[NT][4], f32x4 (&out)[NT][4], char* const (&scrA)[NT], char* const (&scrB)[NT], const char* tab,
+                         const float* Mw) {
     using G = Geo<T, 56>;
     using F = FiltTab<T>;
     constexpr int SZ = G::SZ, LDP = G::LDP, LDV = G::LDV, JC = G::JC, VC = G::VC;
-    const float* Mw = reinterpret_cast<const float*>(tab + F::OFF_MW);
     const int l = lane_id(), w = wave_id();
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -734,7 +746,7 @@ FW_DEV void band_filter2(const f32x4 (&in)[NT][4], f32x4 (&out)[NT][4], char* co
                 store_acc_T<T>(scrB[t] + 32 * LDP, LDP, w * 16, n * 16, ti[t][n]);
             }
     }
-    __syncthreads();
+    lds_barrier();
     if (w < 3) {   // X = Fu T, Y = Mw * X -> [v][u]; waves 0..2 own a 16-row tile of u each, wave 3 clears the k padding u = 48..63
         f32x4 xr[NT][2], xi[NT][2];
 #pragma unroll
@@ -774,7 +786,7 @@ FW_DEV void band_filter2(const f32x4 (&in)[NT][4], f32x4 (&out)[NT][4], char* co
                 if (SZ == 4) *reinterpret_cast<uint4*>(p) = make_uint4(0, 0, 0, 0); else *reinterpret_cast<uint2*>(p) = make_uint2(0, 0);
             }
     }
-    __syncthreads();
+    lds_barrier();
     {   // Z^T[v][i] = sum_u Y^T[v][u] FuH[i][u] (own columns i); FuH = transposed CU / SU panels; stored transposed -> [i][v]
         f32x4 zr[NT][2], zi[NT][2];
 #pragma unroll
@@ -819,7 +831,7 @@ FW_DEV void band_filter2(const f32x4 (&in)[NT][4], f32x4 (&out)[NT][4], char* co
             for (int m = 0; m < 4; ++m) { mma_chunk<T>(out[t][m], ac[m], br); mma_chunk<T>(out[t][m], as[m], bi); }
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // bias + shift mask with the 225 biases of (table, head) in LDS
@@ -834,11 +846,40 @@ FW_DEV float bias_mask_lds(const float* bins, int i, int j, int shift, bool last
     return b;
 }
 
-template <typename T, int D, int LFS> struct Smem2 {
+// DUAL = true : both backward filters in one pass, mask weights on chip, one workgroup per CU (bf16: 111 KB of LDS)
+// DUAL = false: one filter at a time, mask weights from global memory: 79.5 KB -> two workgroups per CU (bf16)
+// The 16 score elements of a lane are the same (query i, key j) pairs in every window: their relative-position biases and
+// whether the pair straddles the cyclic shift's seam vertically / horizontally are computed ONCE per workgroup; per window the
+// -100 mask is one select per element (it applies in the last window row / column only, decoder_Uformer.py:634-651).
+struct BiasRegs {
+    f32x4 b[4];
+    unsigned dy, dx;                                    // bit (jt * 4 + r): i and j lie on different sides of the seam
+    FW_MEM void init(const float* bins, int i, int shift) {
+        const int l = lane_id();
+        dy = dx = 0;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + ((l >> 4) << 2) + r;
+                b[jt][r] = bins[((i >> 3) - (j >> 3) + 7) * 15 + (i & 7) - (j & 7) + 7];
+                if (shift > 0) {
+                    const int s = 8 - shift;
+                    if (((i >> 3) < s) != ((j >> 3) < s)) dy |= 1u << (jt * 4 + r);
+                    if (((i & 7) < s) != ((j & 7) < s)) dx |= 1u << (jt * 4 + r);
+                }
+            }
+    }
+    FW_MEM float get(int jt, int r, unsigned m) const { return b[jt][r] + (((m >> (jt * 4 + r)) & 1) ? -100.0f : 0.0f); }
+    FW_MEM unsigned mask(bool last_y, bool last_x) const { return (last_y ? dy : 0u) | (last_x ? dx : 0u); }
+};
+
+template <typename T, int D, int LFS, bool DUAL = true> struct Smem2 {
     using G = Geo<T, D>;
-    static constexpr int TAB = LFS == 2 ? FiltTab<T>::BYTES : 0;
+    static constexpr bool MW = DUAL || sizeof(T) == 4;
+    static constexpr int TAB = LFS == 2 ? (MW ? FiltTab<T>::BYTES : FiltTab<T>::BYTES_NOMW) : 0;
     static constexpr int SCR = 2 * 64 * G::LDV > 64 * G::LDP ? 2 * 64 * G::LDV : 64 * G::LDP;
-    static constexpr int NTF = (LFS == 2 && sizeof(T) == 2) ? 2 : 1;                 // tiles per backward filter pass
+    static constexpr int NTF = (LFS == 2 && sizeof(T) == 2 && DUAL) ? 2 : 1;         // tiles per backward filter pass
     static constexpr int OFF_BIAS = TAB;
     static constexpr int OFF_T = TAB + 1024;                                          // tiles start here
     static constexpr int RA = SCR > G::TILE_D ? SCR : G::TILE_D;                      // fwd: Q -> P' / scratch A
@@ -861,7 +902,8 @@ __global__ __launch_bounds__(NTH, 1) void attn2_fwd_kernel(AttnArgs a) {
     const int per = (a.nwin + gridDim.x - 1) / gridDim.x;
     const int win_begin = blockIdx.x * per, win_end = min(a.nwin, win_begin + per);
     if (win_begin >= win_end) return;
-    if constexpr (LFS == 2) stage_filter_tables<T>(smem, a.lfs);
+    if constexpr (LFS == 2) stage_filter_tables<T, true>(smem, a.lfs);
+    const float* Mw = reinterpret_cast<const float*>(smem + FiltTab<T>::OFF_MW);
     {
         const float* tb = a.bias + (size_t)(lq * a.L + lq) * 225 * a.heads + h;
         for (int idx = threadIdx.x; idx < 225; idx += NTH) bins[idx] = tb[(size_t)idx * a.heads];
@@ -875,14 +917,19 @@ __global__ __launch_bounds__(NTH, 1) void attn2_fwd_kernel(AttnArgs a) {
         tv.issue(a.v, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
     };
     issue(win_begin);
+    lds_barrier();                          // biases staged
+    BiasRegs br;
+    br.init(bins, i, a.shift);
+    float ca = 1.f, cb = 0.f, cc = 0.f;     // the (image, head)'s LFS coefficients: re-read only when the image changes
+    int cf_b = -1;
     for (int win = win_begin; win < win_end; ++win) {
         const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
         const bool last_y = wy == nWy - 1, last_x = wx == nWx - 1;
         const int nq = lq * a.B + b;
         const size_t item = ((size_t)win * a.L + lq) * a.heads + h;
-        __syncthreads();                    // the previous window's readers are done (also: tables / biases are staged)
+        lds_barrier();                    // the previous window's readers are done (also: tables / biases are staged)
         tq.commit(rA); tk.commit(rB); tv.commit(rV);
-        __syncthreads();
+        lds_barrier();
         if (win + 1 < win_end) issue(win + 1);      // in flight during this window's compute, older than its stores
         f32x4 p[1][4];
 #pragma unroll
@@ -895,12 +942,12 @@ __global__ __launch_bounds__(NTH, 1) void attn2_fwd_kernel(AttnArgs a) {
         }
         {
             float mx = -3.0e38f;
+            const unsigned msk = br.mask(last_y, last_x);
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int j = jt * 16 + ((l >> 4) << 2) + r;
-                    const float sc = p[0][jt][r] * a.scale + bias_mask_lds(bins, i, j, a.shift, last_y, last_x);
+                    const float sc = p[0][jt][r] * a.scale + br.get(jt, r, msk);
                     p[0][jt][r] = sc;
                     mx = fmaxf(mx, sc);
                 }
@@ -916,14 +963,13 @@ __global__ __launch_bounds__(NTH, 1) void attn2_fwd_kernel(AttnArgs a) {
             for (int jt = 0; jt < 4; ++jt) p[0][jt] *= inv;
             if ((l >> 4) == 0) a.lse[item * 64 + i] = mx + __logf(sum);
         }
-        __syncthreads();                    // Q / K tiles are dead from here on
+        lds_barrier();                    // Q / K tiles are dead from here on
         if constexpr (LFS >= 1) {
-            const float* cf = a.coef + ((size_t)b * a.heads + h) * 3;
-            const float ca = cf[0], cb = cf[1], cc = cf[2];
+            if (b != cf_b) { const float* cf = a.coef + ((size_t)b * a.heads + h) * 3; ca = cf[0]; cb = cf[1]; cc = cf[2]; cf_b = b; }
             if constexpr (LFS == 2) {
                 f32x4 f1[1][4];
                 char* const sa[1] = {rA}; char* const sb[1] = {rB};
-                band_filter2<T, 1>(p, f1, sa, sb, tab);
+                band_filter2<T, 1>(p, f1, sa, sb, tab, Mw);
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) p[0][jt] = p[0][jt] * ca + cb + f1[0][jt] * cc;
             } else {
@@ -950,10 +996,10 @@ __global__ __launch_bounds__(NTH, 1) void attn2_fwd_kernel(AttnArgs a) {
     }
 }
 
-template <typename T, int D, int LFS>
+template <typename T, int D, int LFS, bool DUAL>
 __global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
     using G = Geo<T, D>;
-    using S = Smem2<T, D, LFS>;
+    using S = Smem2<T, D, LFS, DUAL>;
     constexpr int NTF = S::NTF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const char* tab = smem;
@@ -968,7 +1014,9 @@ __global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
     const int per = (a.nwin + gridDim.x - 1) / gridDim.x;
     const int win_begin = blockIdx.x * per, win_end = min(a.nwin, win_begin + per);
     if (win_begin >= win_end) return;
-    if constexpr (LFS == 2) stage_filter_tables<T>(smem, a.lfs);
+    if constexpr (LFS == 2) stage_filter_tables<T, S::MW>(smem, a.lfs);
+    const float* Mw = S::MW ? reinterpret_cast<const float*>(smem + FiltTab<T>::OFF_MW)
+                            : reinterpret_cast<const float*>(a.lfs + (size_t)OFF_END * TT<T>::SZ);
     {
         const float* tb = a.bias + (size_t)(lq * a.L + lq) * 225 * a.heads + h;
         for (int idx = threadIdx.x; idx < 225; idx += NTH) bins[idx] = tb[(size_t)idx * a.heads];
@@ -976,7 +1024,7 @@ __global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
     f32x4 dbacc[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) dbacc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
+    float cs1 = 0.f, cs2 = 0.f, cs3 = 0.f, ca = 1.f, cb = 0.f, cc = 0.f;
     int cs_b = -1;
     auto flush_coef = [&]() {
         if constexpr (LFS >= 1) {
@@ -1001,16 +1049,22 @@ __global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
         tv.issue(a.v, a.ld, nq, wy, wx, a.H, a.W, a.shift, h * D);
     };
     issue(win_begin);
+    lds_barrier();                          // biases staged
+    BiasRegs br;
+    br.init(bins, i, a.shift);
     float lse_next = a.lse[(((size_t)win_begin * a.L + lq) * a.heads + h) * 64 + i];
     for (int win = win_begin; win < win_end; ++win) {
         const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
         const bool last_y = wy == nWy - 1, last_x = wx == nWx - 1;
         const int nq = lq * a.B + b;
-        if (b != cs_b) { flush_coef(); cs_b = b; }
+        if (b != cs_b) {
+            flush_coef(); cs_b = b;
+            if constexpr (LFS >= 1) { const float* cf = a.coef + ((size_t)b * a.heads + h) * 3; ca = cf[0]; cb = cf[1]; cc = cf[2]; }
+        }
         const float lse = lse_next;
-        __syncthreads();                    // every wave is past its last read of the previous window's tiles / scratch
+        lds_barrier();                    // every wave is past its last read of the previous window's tiles / scratch
         tq.commit(sQ); tdo.commit(sDO); tk.commit(sK); tv.commit(sV);
-        __syncthreads();
+        lds_barrier();
         if (win + 1 < win_end) {
             issue(win + 1);
             lse_next = a.lse[(((size_t)(win + 1) * a.L + lq) * a.heads + h) * 64 + i];
@@ -1028,32 +1082,25 @@ __global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
                 mma_chunk<T>(pd[1][m], frag_kc(sV, G::LDR, m * 16, c), bd);
             }
         }
+        const unsigned msk = br.mask(last_y, last_x);
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = jt * 16 + ((l >> 4) << 2) + r;
-                pd[0][jt][r] = __expf(pd[0][jt][r] * a.scale + bias_mask_lds(bins, i, j, a.shift, last_y, last_x) - lse);
-            }
-        float ca = 1.f, cb = 0.f, cc = 0.f;
+            for (int r = 0; r < 4; ++r) pd[0][jt][r] = __expf(pd[0][jt][r] * a.scale + br.get(jt, r, msk) - lse);
         f32x4 fg[2][4];                      // [0] = B1(P), [1] = B1(dP')
-        if constexpr (LFS >= 1) {
-            const float* cf = a.coef + ((size_t)b * a.heads + h) * 3;
-            ca = cf[0]; cb = cf[1]; cc = cf[2];
-        }
         if constexpr (LFS == 2) {
             if constexpr (NTF == 2) {
                 char* const sa[2] = {sX, sX2}; char* const sb[2] = {sY, sY2};
-                band_filter2<T, 2>(pd, fg, sa, sb, tab);
+                band_filter2<T, 2>(pd, fg, sa, sb, tab, Mw);
             } else {
                 char* const sa[1] = {sX}; char* const sb[1] = {sY};
                 f32x4 t0[1][4], t1[1][4];
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) t0[0][jt] = pd[0][jt];
-                band_filter2<T, 1>(t0, t1, sa, sb, tab);
+                band_filter2<T, 1>(t0, t1, sa, sb, tab, Mw);
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) { fg[0][jt] = t1[0][jt]; t0[0][jt] = pd[1][jt]; }
-                band_filter2<T, 1>(t0, t1, sa, sb, tab);
+                band_filter2<T, 1>(t0, t1, sa, sb, tab, Mw);
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) fg[1][jt] = t1[0][jt];
             }
@@ -1065,7 +1112,7 @@ __global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
             if constexpr (LFS == 2) pp += fg[0][jt] * cc;
             store_acc_T<T>(sX, G::LDP, jt * 16, w * 16, LFS >= 1 ? pp : pd[0][jt]);
         }
-        __syncthreads();
+        lds_barrier();
         {   // dV^T[d][j] = sum_i dO[i][d] P'[i][j], own columns j
             f32x4 dv[G::DT];
 #pragma unroll
@@ -1106,10 +1153,10 @@ __global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
                 dbacc[jt] += pd[1][jt];
             }
         }
-        __syncthreads();                    // every wave is done reading P' (sX) and its dV staging rows (sY)
+        lds_barrier();                    // every wave is done reading P' (sX) and its dV staging rows (sY)
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) store_acc_T<T>(sX, G::LDP, jt * 16, w * 16, pd[1][jt]);
-        __syncthreads();
+        lds_barrier();
         // dQ^T[d][i] = sum_j K[j][d] dS[i][j] (own i);  dK^T[d][j] = sum_i Q[i][d] dS[i][j] (own j)
         f32x4 dq[G::DT], dk[G::DT];
 #pragma unroll
@@ -1134,10 +1181,10 @@ __global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
         store_rows16<T, D>(sV, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
     }
     flush_coef();
-    __syncthreads();
+    lds_barrier();
     float* fold = reinterpret_cast<float*>(smem + S::OFF_T);          // tiles are dead: fold the (i, j) pairs into the 225 relative positions
     for (int idx = threadIdx.x; idx < 225; idx += NTH) fold[idx] = 0.f;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
@@ -1145,7 +1192,7 @@ __global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
             const int j = jt * 16 + ((l >> 4) << 2) + r;
             atomicAdd(&fold[((i >> 3) - (j >> 3) + 7) * 15 + (i & 7) - (j & 7) + 7], dbacc[jt][r]);
         }
-    __syncthreads();
+    lds_barrier();
     float* dst = a.dbias + (size_t)(lq * a.L + lq) * 225 * a.heads;
     for (int idx = threadIdx.x; idx < 225; idx += NTH) atomicAdd(dst + idx * a.heads + h, fold[idx]);
 }
@@ -1161,16 +1208,22 @@ int fwd2_launch(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((attn2_fwd_kernel<T, D, LFS>), dim3(chunks, a.heads, a.L), dim3(NTH), S::FWD_BYTES, st, a);
     FW_LAUNCH_RET();
 }
-template <typename T, int D, int LFS>
-int bwd2_launch(const AttnArgs& a, hipStream_t st) {
-    using S = Smem2<T, D, LFS>;
-    FW_SET_LDS_ONCE((attn2_bwd_kernel<T, D, LFS>), S::BWD_BYTES);
+template <typename T, int D, int LFS, bool DUAL>
+int bwd2_launch_d(const AttnArgs& a, hipStream_t st) {
+    using S = Smem2<T, D, LFS, DUAL>;
+    FW_SET_LDS_ONCE((attn2_bwd_kernel<T, D, LFS, DUAL>), S::BWD_BYTES);
     const int per_cu = 2 * S::BWD_BYTES <= 160 * 1024 ? 2 : 1;
     int chunks = (256 * per_cu) / (a.heads * a.L);
     if (chunks < 1) chunks = 1;
     if (chunks > a.nwin) chunks = a.nwin;
-    hipLaunchKernelGGL((attn2_bwd_kernel<T, D, LFS>), dim3(chunks, a.heads, a.L), dim3(NTH), S::BWD_BYTES, st, a);
+    hipLaunchKernelGGL((attn2_bwd_kernel<T, D, LFS, DUAL>), dim3(chunks, a.heads, a.L), dim3(NTH), S::BWD_BYTES, st, a);
     FW_LAUNCH_RET();
+}
+template <typename T, int D, int LFS>
+int bwd2_launch(const AttnArgs& a, hipStream_t st) {
+    static const int dual = getenv("FW_ATTN_DUAL") ? atoi(getenv("FW_ATTN_DUAL")) : 1;
+    if constexpr (LFS == 2 && sizeof(T) == 2) { if (!dual) return bwd2_launch_d<T, D, LFS, false>(a, st); }
+    return bwd2_launch_d<T, D, LFS, true>(a, st);
 }
 
 template <typename T, int D, int NKT, int LFS>
@@ -1193,7 +1246,7 @@ template <typename T>
 int dispatch(bool bwd, int D, int nkt, int lfs, const AttnArgs& a, hipStream_t st) {
     static const int v2 = getenv("FW_ATTN_V2") ? atoi(getenv("FW_ATTN_V2")) : 1;              // 0: the v1 kernels for one key tile too
 #define FW_ATT2(DD, FF)                                                                        \
-    if (v2 && D == DD && nkt == 1 && lfs == FF)                                                \
+    if (v2 && D == DD && nkt == 1 && a.mode == 0 && lfs == FF)                                 \
         return bwd ? bwd2_launch<T, DD, FF>(a, st) : fwd2_launch<T, DD, FF>(a, st);
     FW_ATT2(56, 0) FW_ATT2(56, 1) FW_ATT2(56, 2) FW_ATT2(28, 0) FW_ATT2(64, 0)
 #undef FW_ATT2

@@ -34,7 +34,14 @@ FW_DEV bf16raw f2bf(float f) {
     __bf16 h = (__bf16)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return __builtin_bit_cast(bf16raw, h);
 }
-FW_DEV unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+// two floats -> one dword of bf16: ONE v_cvt_pk_bf16_f32 (RNE, NaN stays NaN); converting the halves separately costs
+// two conversions and an OR per pair, and the pair conversion runs in every epilogue and every LDS transpose store
+typedef __attribute__((ext_vector_type(2))) float fw_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 fw_bf16x2;
+FW_DEV unsigned pack_bf2(float lo, float hi) {
+    const fw_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, fw_bf16x2));
+}
 
 template <typename T> struct TT;
 template <> struct TT<float> {

@@ -76,6 +76,13 @@ def shadow(param, kind='plain'):
         ci, co = p.shape[0], p.shape[1]
         out = torch.empty((4 * co, ci), dtype=dtype, device=p.device)
         ops.permute3(p.contiguous(), out, (ci, co, 4), (1, ci, co * ci))
+    elif kind in ('leff1', 'leff2'):
+        # operand panels of the fused LeFF kernel (fw_leff_fwd): linear1 [4C][roundup(C, 32)] with zero-padded K;
+        # linear2 [roundup(C, 16) + 1][4C] with zero rows (one spare row: the last chunk's fragment reads run 16 elements on)
+        n, k = p.shape
+        rows, cols = (n, (k + 31) // 32 * 32) if kind == 'leff1' else ((n + 15) // 16 * 16 + 1, k)
+        out = torch.zeros((rows, cols), dtype=torch.bfloat16, device=p.device)
+        call('fw_cast_rows', 1, p, k, out, cols, n, k, None, 1)
     else:
         raise ValueError(kind)
     if ent is None:
@@ -151,18 +158,23 @@ class LinearFn(torch.autograd.Function):
     out_f32: y is f32."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, rowscale, rows_per_scale, x_pre, gelu_out, out_f32):
+    def forward(ctx, x, weight, bias, residual, rowscale, rows_per_scale, x_pre, gelu_out, out_f32, fuse=None):
         ctx.set_materialize_grads(False)            # the GELU twin never gets a gradient: do not zero-fill one for it
         M, K = x.shape
         N = weight.shape[0]
-        w = shadow(weight)
-        if residual is not None or out_f32:
-            y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        if fuse is not None and not gelu_out:       # linear2 of a fused LeFF: fw_leff_fwd already produced y (see `leff_fused`)
+            y, g = fuse['y'], None
+        elif fuse is not None:                      # linear1 of a fused LeFF: ONE kernel computes the whole feed-forward
+            y, g = _leff_fused_forward(x, weight, bias, fuse)
         else:
-            y = act_empty(M, N, x.dtype, x.device)
-        g = act_empty(M, N, x.dtype, x.device) if gelu_out else None
-        ops.gemm(x, w, M, N, K, out=y, bias=bias, rowscale=rowscale, rows_per_scale=rows_per_scale, residual=residual,
-                 out_gelu=g)
+            w = shadow(weight)
+            if residual is not None or out_f32:
+                y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+            else:
+                y = act_empty(M, N, x.dtype, x.device)
+            g = act_empty(M, N, x.dtype, x.device) if gelu_out else None
+            ops.gemm(x, w, M, N, K, out=y, bias=bias, rowscale=rowscale, rows_per_scale=rows_per_scale, residual=residual,
+                     out_gelu=g)
         ctx.save_for_backward(x, weight, rowscale, x_pre)
         ctx.bias = bias
         ctx.cfg = (rows_per_scale, residual is not None)
@@ -174,7 +186,7 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *_):
         if dy is None:
-            return (None,) * 9
+            return (None,) * 10
         x, weight, rowscale, x_pre = ctx.saved_tensors
         rows_per_scale, has_res = ctx.cfg
         bias = ctx.bias
@@ -198,7 +210,24 @@ class LinearFn(torch.autograd.Function):
                 dpre = d
             else:
                 dx = d
-        return dx, dw, db, (dy if has_res else None), None, None, dpre, None, None
+        return dx, dw, db, (dy if has_res else None), None, None, dpre, None, None, None
+
+
+def _leff_fused_forward(xn, w1, b1, fuse):
+    """fw_leff_fwd: y = res + rowscale * linear2(GELU(dwconv(GELU(linear1(xn))))) in one kernel; returns (h1, g1) -- the outputs
+    of the linear1 node -- and leaves h2, g2, y in `fuse` for the DwConvFn / LinearFn nodes that follow (they keep their own
+    backward; only their forward launches are replaced)."""
+    M, C = xn.shape
+    B, H, W = fuse['geo']
+    C4 = w1.shape[0]
+    h1, g1 = act_empty(M, C4, xn.dtype, xn.device), act_empty(M, C4, xn.dtype, xn.device)
+    h2, g2 = act_empty(M, C4, xn.dtype, xn.device), act_empty(M, C4, xn.dtype, xn.device)
+    y = torch.empty((M, C), dtype=torch.float32, device=xn.device)
+    res, rs = fuse['residual'], fuse['rowscale']
+    call('fw_leff_fwd', xn, xn.stride(0), shadow(w1, 'leff1'), b1, shadow(fuse['wd'], 'dw9'), fuse['bd'], shadow(fuse['w2'], 'leff2'), fuse['b2'],
+         res, res.stride(0), rs, fuse['rows_per_scale'], y, y.stride(0), h1, g1, h2, g2, h1.stride(0), B, H, W, C)
+    fuse['h2'], fuse['g2'], fuse['y'] = h2, g2, y
+    return h1, g1
 
 
 class LnResFn(torch.autograd.Function):
@@ -239,8 +268,8 @@ class LnResFn(torch.autograd.Function):
         return dx, rg, rb
 
 
-def linear(x, weight, bias=None, residual=None, rowscale=None, rows_per_scale=1, x_pre=None, gelu_out=False, out_f32=False):
-    y = LinearFn.apply(x, weight, bias, residual, rowscale, rows_per_scale, x_pre, gelu_out, out_f32)
+def linear(x, weight, bias=None, residual=None, rowscale=None, rows_per_scale=1, x_pre=None, gelu_out=False, out_f32=False, fuse=None):
+    y = LinearFn.apply(x, weight, bias, residual, rowscale, rows_per_scale, x_pre, gelu_out, out_f32, fuse)
     if residual is not None and y.requires_grad and (x.dtype != torch.float32 or rowscale is not None):
         y._fw_rs = (rowscale, rows_per_scale)               # lets the LayerNorm that consumes y emit this Linear's backward operand
     return y
@@ -359,13 +388,16 @@ class DwConvFn(torch.autograd.Function):
     d h2 (LinearFn routes it there via x_pre) and returns d h1."""
 
     @staticmethod
-    def forward(ctx, h1, g1, weight, bias, B, H, W):
+    def forward(ctx, h1, g1, weight, bias, B, H, W, fuse=None):
         ctx.set_materialize_grads(False)
         C = h1.shape[1]
-        h2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
-        g2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
         wt = shadow(weight, 'dw9')                                               # tap-major copy of the [C,1,3,3] weight, cached per step
-        call('fw_dwconv_fwd', dt(h1.dtype), g1, g1.stride(0), wt, bias, h2, g2, h2.stride(0), B, H, W, C)
+        if fuse is not None:                                                     # fused LeFF forward: fw_leff_fwd already wrote both
+            h2, g2 = fuse['h2'], fuse['g2']
+        else:
+            h2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
+            g2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
+            call('fw_dwconv_fwd', dt(h1.dtype), g1, g1.stride(0), wt, bias, h2, g2, h2.stride(0), B, H, W, C)
         ctx.save_for_backward(h1, g1, weight, wt)
         ctx.bias = bias
         ctx.geo = (B, H, W)
@@ -375,7 +407,7 @@ class DwConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh2, _):
         if dh2 is None:
-            return (None,) * 7
+            return (None,) * 8
         h1, g1, weight, wt = ctx.saved_tensors
         B, H, W = ctx.geo
         C = h1.shape[1]
@@ -384,7 +416,7 @@ class DwConvFn(torch.autograd.Function):
         dw, rw = _grad_target(weight, (C, 9))                                    # the kernel adds in the parameter's layout
         dh1 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
         call('fw_dwconv_bwd', dt(h1.dtype), dh2, dh2.stride(0), g1, h1, h1.stride(0), wt, dh1, dh1.stride(0), dw, db, B, H, W, C)
-        return dh1, None, (rw.view_as(weight) if rw is not None else None), rb, None, None, None
+        return dh1, None, (rw.view_as(weight) if rw is not None else None), rb, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@ from . import ops
 from .lib import call
 
 WIN = 8
+_LEFF_FUSED_MIN_ROWS = int(os.environ.get('FW_LEFF_FUSED_MIN_ROWS', '32768'))      # tokens from which LeFF.run takes the fused forward kernel
 
 
 def trunc_normal_(t, std=.02):
@@ -60,12 +61,19 @@ class LeFF(nn.Module):
         self.linear2 = nn.Sequential(nn.Linear(hidden_dim, dim))
 
     def run(self, xn, residual, rowscale, batch):
-        rows = xn.shape[0]
+        rows, C = xn.shape
         h = _tokens_hw(rows, batch)
-        h1, g1 = Fn.linear(xn, self.linear1[0].weight, self.linear1[0].bias, gelu_out=True)
-        h2, g2 = Fn.DwConvFn.apply(h1, g1, self.conv[0].weight, self.conv[0].bias, batch, h, h)
+        fuse = None
+        if (xn.dtype == torch.bfloat16 and C in (28, 56, 112) and h % 16 == 0 and rows >= _LEFF_FUSED_MIN_ROWS
+                and self.linear1[0].weight.shape[0] == 4 * C):
+            # high-resolution stages: the whole feed-forward in one kernel (csrc/fw_leff.hip); the three autograd nodes below
+            # keep their backward passes, only their forward launches collapse into the first one
+            fuse = dict(geo=(batch, h, h), residual=residual, rowscale=rowscale, rows_per_scale=h * h, wd=self.conv[0].weight,
+                        bd=self.conv[0].bias, w2=self.linear2[0].weight, b2=self.linear2[0].bias)
+        h1, g1 = Fn.linear(xn, self.linear1[0].weight, self.linear1[0].bias, gelu_out=True, fuse=fuse)
+        h2, g2 = Fn.DwConvFn.apply(h1, g1, self.conv[0].weight, self.conv[0].bias, batch, h, h, fuse)
         return Fn.linear(g2, self.linear2[0].weight, self.linear2[0].bias, residual=residual, rowscale=rowscale,
-                         rows_per_scale=h * h, x_pre=h2)
+                         rows_per_scale=h * h, x_pre=h2, fuse=fuse)
 
     def forward(self, x):                       # API parity: [B, HW, C] f32 -> [B, HW, C]
         B, HW, C = x.shape

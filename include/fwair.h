@@ -232,6 +232,15 @@ int fw_small_linear_fwd(const float* x, const float* w, const float* b, float* y
 int fw_small_linear_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, int M, int N,
                         int K, float slope, void* stream);
 
+/* ---- fused LeFF forward (net/utils/leff.py:92-117) for the high-resolution stages, bf16 operands ----------------------------
+ * y = res + rowscale * linear2(GELU(dwconv3x3(GELU(linear1(xn))))) in one kernel per 8 x 16 pixel patch: the hidden tensor is
+ * produced and consumed on chip (7 chunks of 4C/7 channels); h1, g1, h2, g2 (bf16 [T][4C]) are WRITTEN for the unfused backward
+ * kernels, never re-read.  w1p: bf16 [4C][roundup(C, 32)] zero-padded; w2p: bf16 [roundup(C, 16) + 1][4C] zero rows;
+ * wd: f32 [9][4C] tap-major.  C in {28, 56, 112}, H % 8 == 0, W % 16 == 0. */
+int fw_leff_fwd(const void* xn, long ldx, const void* w1p, const float* b1, const float* wd, const float* bd, const void* w2p,
+                const float* b2, const float* res, long ldr, const float* rowscale, int rows_per_scale, float* y, long ldy, void* h1,
+                void* g1, void* h2, void* g2, long ldh, int B, int H, int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -720,3 +720,56 @@ def test_dwconv_tiled_kernel_timed_shape(dtype):
     # 262 144 pixels summed per tap: f32 atomics of block partials; bf16 operands carry 8 bits each
     close(dw, w.grad.view(C, 9), TOL[dtype] * 4, 'dw')
     close(db, b.grad, TOL[dtype] * 4, 'db')
+
+
+# ------------------------------------------------------------------------------------------------ fused LeFF forward
+@pytest.mark.parametrize('C,H,B', [(112, 32, 2), (56, 16, 3), (28, 48, 2)])
+def test_leff_fused_forward_matches_unfused_and_reference(C, H, B):
+    """csrc/fw_leff.hip (linear1 + GELU + depthwise 3x3 + GELU + linear2 + DropPath + residual in one kernel, bf16) against the
+    unfused kernel chain on the same module (outputs, saved twins, every gradient) and against the fp32 PyTorch statement of
+    net/utils/leff.py:92-117.  The backward pass is the unfused one in both runs: it consumes the tensors the fused kernel wrote."""
+    from fwair import functional as Fn
+    from fwair import modules as Mo
+    Fn.config.compute_dtype = torch.bfloat16
+    Fn.config.direct_grads = False
+    torch.manual_seed(C)
+    leff = Mo.LeFF(C, 4 * C).to(DEV)
+    with torch.no_grad():
+        for p_ in leff.parameters():
+            p_.copy_(q(p_ * 2.0 + (0.05 if p_.dim() == 1 else 0.0), torch.bfloat16))
+    rows = B * H * H
+    xn = q(rnd(rows, C), torch.bfloat16)
+    res = rnd(rows, C, seed=1)
+    scale = torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.9][:B])
+    dy = rnd(rows, C, seed=2)
+    outs = []
+    keep = Mo._LEFF_FUSED_MIN_ROWS
+    try:
+        for fused in (True, False):
+            Mo._LEFF_FUSED_MIN_ROWS = 0 if fused else 1 << 40
+            for p_ in leff.parameters():
+                p_.grad = None
+            x_ = Fn.act_empty(rows, C, torch.bfloat16, DEV)
+            x_.copy_(xn.to(DEV, torch.bfloat16))
+            x_.requires_grad_(True)
+            r_ = res.to(DEV).requires_grad_(True)
+            y = leff.run(x_, r_, scale.to(DEV), B)
+            y.backward(dy.to(DEV))
+            outs.append((y.detach().cpu(), x_.grad.float().cpu(), r_.grad.cpu(), [p_.grad.detach().cpu().clone() for p_ in leff.parameters()]))
+    finally:
+        Mo._LEFF_FUSED_MIN_ROWS = keep
+        Fn.config.compute_dtype = torch.float32
+    (yf, dxf, drf, gf), (yu, dxu, dru, gu) = outs
+    close(yf, yu, 4e-3, 'fused y vs unfused y')             # bf16 hidden tensors: GELU inputs rounded at slightly different points
+    close(dxf, dxu, 2e-2, 'dx through the tensors the fused kernel saved')
+    close(drf, dru, 1e-6, 'd residual')
+    for a_, b_, (n_, _) in zip(gf, gu, leff.named_parameters()):
+        close(a_, b_, 2e-2, 'grad ' + n_)
+    # fp32 statement of the reference
+    w1, b1 = leff.linear1[0].weight.detach().cpu(), leff.linear1[0].bias.detach().cpu()
+    wd, bd = leff.conv[0].weight.detach().cpu(), leff.conv[0].bias.detach().cpu()
+    w2, b2 = leff.linear2[0].weight.detach().cpu(), leff.linear2[0].bias.detach().cpu()
+    h = F.gelu(F.linear(xn, w1, b1)).view(B, H, H, 4 * C).permute(0, 3, 1, 2)
+    h = F.gelu(F.conv2d(h, wd, bd, padding=1, groups=4 * C)).permute(0, 2, 3, 1).reshape(rows, 4 * C)
+    ref = res + F.linear(h, w2, b2) * scale.repeat_interleave(H * H)[:, None]
+    close(yf, ref, 2e-2, 'fused y vs fp32 reference')

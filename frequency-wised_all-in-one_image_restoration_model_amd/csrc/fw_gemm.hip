@@ -557,6 +557,69 @@ __global__ __launch_bounds__(256) void gemm_tr_kernel(GemmArgs a) {
     }
 }
 
+// Epilogue of a 128 x (64 * 4 / WM ... ) wave tile: acc[nt][mt] holds C[m = .. + mt*16 + (l & 15)][n0 = .. + nt*16 + 4*(l >> 4) .. +3].
+// PLAIN = true is the specialisation for the launches that need nothing but `+ bias` and a store (QKV / projection forward,
+// input gradients, split-K partial tiles: most launches of a step): about 10 instructions per quad instead of the ~50 of the
+// general form, whose run-time switches (activation, DropPath scale, residual, GELU twin, accumulate) cost as much VALU issue as
+// the MFMAs of a 7-step K loop.
+template <typename T, int WM, bool PLAIN>
+FW_DEV void tile_epilogue(const GemmArgs& a, const f32x4 (&acc)[4][WM], int m_blk, int n_blk, int wm0, int wn0, int bz) {
+    const int l = lane_id();
+    f32x4 bias4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+        bias4[nt] = epi_bias(a, n0 < a.N ? n0 : 0, bz);
+    }
+    if constexpr (PLAIN) {
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+            const int m = m_blk + wm0 + mt * 16 + (l & 15);
+            if (m >= a.M) continue;
+            if (a.out_f32) {
+                float* cp = reinterpret_cast<float*>(a.C) + (long)bz * a.c_zstride + (long)m * a.ldc;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+                    if (n0 < a.N) *reinterpret_cast<f32x4*>(cp + n0) = acc[nt][mt] + bias4[nt];
+                }
+            } else {
+                T* cp = reinterpret_cast<T*>(a.C) + (long)m * a.ldc;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+                    if (n0 < a.N) {
+                        const f32x4 v = acc[nt][mt] + bias4[nt];
+                        if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(cp + n0) = v;
+                        else *reinterpret_cast<uint2*>(cp + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+            const int m = m_blk + wm0 + mt * 16 + (l & 15);
+            const int mc = m < a.M ? m : a.M - 1;
+            const float rs = a.rowscale ? a.rowscale[mc / a.rows_per_scale] : 1.0f;
+            uint4 ext[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+                epi_fetch<T>(a, ext[nt], mc, n0 < a.N ? n0 : 0, bz);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+                if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], ext[nt], acc[nt][mt], m, n0, rs, bz);
+            }
+        }
+    }
+}
+static inline bool plain_epilogue(const GemmArgs& a) {
+    return a.act == 0 && !a.rowscale && !a.residual && !a.C2 && a.alpha == 1.0f && !(a.accumulate && a.c_zstride == 0);
+}
+
 // ---- the same product with a DEEP global -> LDS pipeline ------------------------------------------------------------
 // gemm_tr_kernel above keeps ONE stage in flight per workgroup and drains it (`__syncthreads()` = vmcnt(0)) every K step: with
 // two workgroups per CU a step costs one L2 / fabric round trip (1.4 us for 32 KB measured in the B = 16 step), i.e. the kernel
@@ -628,7 +691,7 @@ template <typename T, int ROWS> struct GldsKc {
     }
 };
 
-template <bool XT, int KT, int NS>
+template <bool XT, int KT, int NS, bool PLAIN>
 __global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
     using T = bf16raw;
     static_assert(XT || KT == 64, "the k-contiguous X image is built for 64-deep steps");
@@ -726,43 +789,25 @@ __global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
             }
         }
     }
-    f32x4 bias4[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
-        bias4[nt] = epi_bias(a, n0 < a.N ? n0 : 0, bz);
-    }
-#pragma unroll
-    for (int mt = 0; mt < WM; ++mt) {
-        const int m = m_blk + wm0 + mt * 16 + (l & 15);
-        const int mc = m < a.M ? m : a.M - 1;
-        const float rs = a.rowscale ? a.rowscale[mc / a.rows_per_scale] : 1.0f;
-        uint4 ext[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
-            epi_fetch<T>(a, ext[nt], mc, n0 < a.N ? n0 : 0, bz);
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
-            if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], ext[nt], acc[nt][mt], m, n0, rs, bz);
-        }
-    }
+    tile_epilogue<T, WM, PLAIN>(a, acc, m_blk, n_blk, wm0, wn0, bz);
 }
 
+template <bool XT, int KT, int NS, bool PLAIN>
+int launch_tr_ring_p(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)NS * ((XT ? KT * 256 : 128 * LDS_ROW) + KT * 256);
+    FW_SET_LDS_ONCE((gemm_tr_ring_kernel<XT, KT, NS, PLAIN>), lds);
+    hipLaunchKernelGGL((gemm_tr_ring_kernel<XT, KT, NS, PLAIN>), dim3(fw_cdiv(a.M, 128), fw_cdiv(a.N, 128), a.splitk), dim3(256), lds, st, a);
+    FW_LAUNCH_RET();
+}
 template <bool XT, int KT, int NS>
 int launch_tr_ring(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)NS * ((XT ? KT * 256 : 128 * LDS_ROW) + KT * 256);
-    FW_SET_LDS_ONCE((gemm_tr_ring_kernel<XT, KT, NS>), lds);
-    hipLaunchKernelGGL((gemm_tr_ring_kernel<XT, KT, NS>), dim3(fw_cdiv(a.M, 128), fw_cdiv(a.N, 128), a.splitk), dim3(256), lds, st, a);
-    FW_LAUNCH_RET();
+    return plain_epilogue(a) ? launch_tr_ring_p<XT, KT, NS, true>(a, st) : launch_tr_ring_p<XT, KT, NS, false>(a, st);
 }
 
 // ---- gemm_kernel's NT product (both operands k-contiguous, whole 128-byte K steps) on the same ring ---------------------
 // Forward Linears of the C >= 224 stages, im2col / pixel-shuffle convolutions: y = x W^T.  Stage = [128 + BN rows][128 B].
 // BN = 128: 4 stages of 32 KB (1 workgroup per CU, 96 KB in flight); BN = 64: 3 stages of 24 KB (2 workgroups per CU).
-template <typename T, int BN, int NS>
+template <typename T, int BN, int NS, bool PLAIN>
 __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a) {
     constexpr int KT = 128 / TT<T>::SZ;
     constexpr int WM = (BN == 128) ? 4 : 2;
@@ -835,38 +880,20 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a) {
         buf = buf + 1 == NS ? 0 : buf + 1;
     }
     const int l = lane_id();
-    f32x4 bias4[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
-        bias4[nt] = epi_bias(a, n0 < a.N ? n0 : 0, bz);
-    }
-#pragma unroll
-    for (int mt = 0; mt < WM; ++mt) {
-        const int m = m_blk + wm0 + mt * 16 + (l & 15);
-        const int mc = m < a.M ? m : a.M - 1;
-        const float rs = a.rowscale ? a.rowscale[mc / a.rows_per_scale] : 1.0f;
-        uint4 ext[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
-            epi_fetch<T>(a, ext[nt], mc, n0 < a.N ? n0 : 0, bz);
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
-            if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], ext[nt], acc[nt][mt], m, n0, rs, bz);
-        }
-    }
+    tile_epilogue<T, WM, PLAIN>(a, acc, m_blk, n_blk, wm0, wn0, bz);
 }
 
+template <typename T, int BN, int NS, bool PLAIN>
+int launch_ring_p(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)NS * (BM + BN) * LDS_ROW;
+    FW_SET_LDS_ONCE((gemm_ring_kernel<T, BN, NS, PLAIN>), lds);
+    dim3 grid(fw_cdiv(a.M, BM), fw_cdiv(a.N, BN), a.splitk);
+    hipLaunchKernelGGL((gemm_ring_kernel<T, BN, NS, PLAIN>), grid, dim3(256), lds, st, a);
+    FW_LAUNCH_RET();
+}
 template <typename T, int BN, int NS>
 int launch_ring(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)NS * (BM + BN) * LDS_ROW;
-    FW_SET_LDS_ONCE((gemm_ring_kernel<T, BN, NS>), lds);
-    dim3 grid(fw_cdiv(a.M, BM), fw_cdiv(a.N, BN), a.splitk);
-    hipLaunchKernelGGL((gemm_ring_kernel<T, BN, NS>), grid, dim3(256), lds, st, a);
-    FW_LAUNCH_RET();
+    return plain_epilogue(a) ? launch_ring_p<T, BN, NS, true>(a, st) : launch_ring_p<T, BN, NS, false>(a, st);
 }
 
 template <bool XT>

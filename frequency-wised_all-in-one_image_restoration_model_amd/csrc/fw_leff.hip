@@ -19,6 +19,7 @@
 //     recomputing backward would drop them: next step.)
 // Weight fragments are read straight from L2 / L1 (W1: 4C x C, W2: C x 4C: 100 KB together at C = 112, shared by all workgroups).
 #include "fw_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -42,6 +43,7 @@ constexpr int LTH = 512;
 
 template <int CW>
 __global__ __launch_bounds__(LTH, 2) void leff_fwd_kernel(LeffArgs a) {
+    const bool twins = a.ldh > 0;                        // probe only (tools/leff_probe.py): ldh = 0 skips the four twin stores
     constexpr int CT = CW / 16;                          // MFMA column tiles per hidden chunk
     constexpr int KG = CW < 32 ? 32 : CW;                // k extent of GEMM 2's operand rows (zero-padded for CW = 16)
     constexpr int LDG1 = CW * 2 + 16;                    // g1 rows (bytes)
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(LTH, 2) void leff_fwd_kernel(LeffArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { hv[q] = acc[q] + bb[q]; gv[q] = gelu_f(hv[q]); }
                 *reinterpret_cast<uint2*>(g1s + p * LDG1 + cl * 2) = inimg ? make_uint2(pack_bf2(gv[0], gv[1]), pack_bf2(gv[2], gv[3])) : make_uint2(0, 0);
-                if (inimg && py >= 1 && py <= LT_Y && px >= 1 && px <= LT_X) {      // centre pixel: this tile owns its h1 / g1
+                if (twins && inimg && py >= 1 && py <= LT_Y && px >= 1 && px <= LT_X) {      // centre pixel: this tile owns its h1 / g1
                     const long row = img0 + (long)iy * a.W + ix;
                     *reinterpret_cast<uint2*>(a.h1 + row * a.ldh + hc0 + cl) = make_uint2(pack_bf2(hv[0], hv[1]), pack_bf2(hv[2], hv[3]));
                     *reinterpret_cast<uint2*>(a.g1 + row * a.ldh + hc0 + cl) = make_uint2(pack_bf2(gv[0], gv[1]), pack_bf2(gv[2], gv[3]));
@@ -147,8 +149,10 @@ __global__ __launch_bounds__(LTH, 2) void leff_fwd_kernel(LeffArgs a) {
                     const uint2 hp = make_uint2(pack_bf2(s[e0], s[e0 + 1]), pack_bf2(s[e0 + 2], s[e0 + 3]));
                     const uint2 gp = make_uint2(pack_bf2(g0, g1v), pack_bf2(g2v, g3));
                     *reinterpret_cast<uint2*>(g2s + p * LDG2 + (cg + e0) * 2) = gp;
-                    *reinterpret_cast<uint2*>(a.h2 + row * a.ldh + hc0 + cg + e0) = hp;
-                    *reinterpret_cast<uint2*>(a.g2 + row * a.ldh + hc0 + cg + e0) = gp;
+                    if (twins) {
+                        *reinterpret_cast<uint2*>(a.h2 + row * a.ldh + hc0 + cg + e0) = hp;
+                        *reinterpret_cast<uint2*>(a.g2 + row * a.ldh + hc0 + cg + e0) = gp;
+                    }
                 }
             }
             __syncthreads();
@@ -201,7 +205,9 @@ extern "C" int fw_leff_fwd(const void* xn, long ldx, const void* w1p, const floa
                            void* h1, void* g1, void* h2, void* g2, long ldh, int B, int H, int W, int C, void* stream) {
     FW_CHECK_ARG(xn && w1p && b1 && wd && bd && w2p && b2 && res && y && h1 && g1 && h2 && g2);
     FW_CHECK_ARG((C == 28 || C == 56 || C == 112) && H % 8 == 0 && W % 16 == 0 && B > 0);
-    FW_CHECK_ARG(ldx % 8 == 0 && ldh % 4 == 0 && ldh >= 4 * C && ldr % 4 == 0 && ldy % 4 == 0 && (!rowscale || rows_per_scale > 0));
+    static const bool nostore = getenv("FW_LEFF_NOSTORE") != nullptr;
+    if (nostore) ldh = 0;
+    FW_CHECK_ARG(ldx % 8 == 0 && ldh % 4 == 0 && (ldh >= 4 * C || nostore) && ldr % 4 == 0 && ldy % 4 == 0 && (!rowscale || rows_per_scale > 0));
     FW_CHECK_ARG(((uintptr_t)xn & 15) == 0 && ((uintptr_t)w1p & 15) == 0 && ((uintptr_t)w2p & 15) == 0 && ((uintptr_t)res & 15) == 0 &&
                  ((uintptr_t)y & 15) == 0 && ((uintptr_t)b1 & 15) == 0 && ((uintptr_t)b2 & 15) == 0);
     LeffArgs a;

@@ -20,7 +20,11 @@ from . import ops
 from .lib import call
 
 WIN = 8
-_LEFF_FUSED_MIN_ROWS = int(os.environ.get('FW_LEFF_FUSED_MIN_ROWS', '32768'))      # tokens from which LeFF.run takes the fused forward kernel
+# Tokens from which LeFF.run takes the fused forward kernel (csrc/fw_leff.hip).  OFF by default: measured on MI355X the fused kernel
+# LOSES to the unfused chain on every high-resolution stage (tools/leff_probe.py: 1050 vs 490 us at C = 112, 262 144 tokens; 901 us
+# even with its four twin stores removed) -- the 1.5x halo of GELU evaluations and the per-chunk weight fragments from L2 cost more
+# than the hidden tensor's round trips through 6 TB/s of HBM save, and the unfused backward needs the twins written anyway.
+_LEFF_FUSED_MIN_ROWS = int(os.environ.get('FW_LEFF_FUSED_MIN_ROWS', str(1 << 62)))
 
 
 def trunc_normal_(t, std=.02):

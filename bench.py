@@ -11,6 +11,7 @@ denoise sigma = 25, 128x128, batch 16 per GPU, bf16 operands / f32 accumulation.
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -132,7 +133,9 @@ def gemm_profile(engine, batch, reps=8):
         x, w, kw = sets[0]
         with torch.cuda.stream(side):
             orig(x, w, M, N, K, **kw)
-            code = L.fw_gemm_last_variant()                   # the kernel fw_gemm really chose (names as in the rocprofv3 stats)
+            nbuf = ctypes.create_string_buffer(96)
+            L.fw_gemm_last_kernel(nbuf, 96)                   # the kernel fw_gemm really chose (named as in the rocprofv3 stats)
+            kern = nbuf.value.decode()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
@@ -158,8 +161,7 @@ def gemm_profile(engine, batch, reps=8):
         for key in ('residual', 'aux', 'out_gelu'):
             if kw.get(key) is not None:
                 by += M * N * kw[key].element_size()
-        fam, bn, xt, wt = code // 100000, code // 100 % 1000, bool(code // 10 % 10), bool(code % 10)
-        variant = ('bf16' if x.dtype == torch.bfloat16 else 'f32', ('stream', 'tr')[2 - fam] if fam else bn, xt, wt)
+        variant = ('bf16' if x.dtype == torch.bfloat16 else 'f32', kern)
         out.append((variant, (M, N, K, sk), cnt, 2.0 * M * N * K, float(by), dt, float(over)))
         del g, sets, kw, x, w
     agg = {}
@@ -171,10 +173,10 @@ def gemm_profile(engine, batch, reps=8):
     dump = os.environ.get('FW_GEMM_DUMP')
     if dump:
         with open(dump, 'w') as f:
-            f.write('dtype,kernel,xT,wT,M,N,K,splitk,launches_per_step,us_per_launch,ms_per_step,TFLOPs,GBs,roofline_us\n')
+            f.write('dtype,kernel,M,N,K,splitk,launches_per_step,us_per_launch,ms_per_step,TFLOPs,GBs,roofline_us\n')
             for v, sh, cnt, fl, by, dt, _ in sorted(out, key=lambda r: -r[2] * r[5]):
                 roof = max(fl / PEAK_FOR[v[0]], by / PEAK_HBM) * 1e6
-                f.write(f'{v[0]},{v[1]},{int(v[2])},{int(v[3])},{sh[0]},{sh[1]},{sh[2]},{sh[3]},{cnt},{dt * 1e6:.1f},'
+                f.write(f'{v[0]},"{v[1]}",{sh[0]},{sh[1]},{sh[2]},{sh[3]},{cnt},{dt * 1e6:.1f},'
                         f'{dt * cnt * 1e3:.3f},{fl / dt / 1e12:.1f},{by / dt / 1e9:.0f},{roof:.1f}\n')
     return agg, len(rec)
 
@@ -479,8 +481,7 @@ def main():
         # the variant's launches are priced one by one against max(FLOPs / MFMA peak, bytes / HBM peak); `bound` is the
         # side that sets most of that time, `achieved` / `peak` are quoted in its unit, `frac` = roofline time / measured
         hbm = by / PEAK_HBM > fl / peak
-        kname = (f'gemm_stream_kernel<{v[0]},wT={int(v[3])}>' if v[1] == 'stream' else f'gemm_tr_kernel<xT={int(v[2])}>' if v[1] == 'tr'
-                 else f'gemm_kernel<{v[0]},BN={v[1]},xT={int(v[2])},wT={int(v[3])}>')
+        kname = v[1]
         traffic, prov = pmc_traffic(kname)
         ach = (by / tt / 1e9) if hbm else (fl / tt / 1e12)
         pk = (PEAK_HBM / 1e9) if hbm else (peak / 1e12)

@@ -16,9 +16,17 @@
 // with 4 CONSECUTIVE n for one m: bias / residual / output are 8- and 16-byte vector accesses.
 // bf16 uses v_mfma_f32_16x16x32_bf16, f32 uses v_mfma_f32_16x16x4_f32 (exact f32), same code.
 #include "fw_common.h"
+#include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 namespace {
+// name of the kernel the last fw_gemm call of this thread launched, spelt like rocprofv3's demangled kernel names with spaces
+// removed and "unsigned short" written bf16 (measurement aid: bench.py and tools/pmc_summary.py key their per-kernel rows on it)
+static thread_local char g_last_kernel[96] = "";
+template <typename T> constexpr const char* tname() { return sizeof(T) == 2 ? "bf16" : "float"; }
+#define FW_B(x) ((x) ? "true" : "false")
+#define FW_KNAME(...) snprintf(g_last_kernel, sizeof g_last_kernel, __VA_ARGS__)
 
 struct GemmArgs {
     const char* X; const char* W; char* C;
@@ -796,6 +804,7 @@ template <bool XT, int KT, int NS, bool PLAIN>
 int launch_tr_ring_p(const GemmArgs& a, hipStream_t st) {
     const size_t lds = (size_t)NS * ((XT ? KT * 256 : 128 * LDS_ROW) + KT * 256);
     FW_SET_LDS_ONCE((gemm_tr_ring_kernel<XT, KT, NS, PLAIN>), lds);
+    FW_KNAME("gemm_tr_ring_kernel<%s,%d,%d,%s>", FW_B(XT), KT, NS, FW_B(PLAIN));
     hipLaunchKernelGGL((gemm_tr_ring_kernel<XT, KT, NS, PLAIN>), dim3(fw_cdiv(a.M, 128), fw_cdiv(a.N, 128), a.splitk), dim3(256), lds, st, a);
     FW_LAUNCH_RET();
 }
@@ -888,6 +897,7 @@ int launch_ring_p(const GemmArgs& a, hipStream_t st) {
     const size_t lds = (size_t)NS * (BM + BN) * LDS_ROW;
     FW_SET_LDS_ONCE((gemm_ring_kernel<T, BN, NS, PLAIN>), lds);
     dim3 grid(fw_cdiv(a.M, BM), fw_cdiv(a.N, BN), a.splitk);
+    FW_KNAME("gemm_ring_kernel<%s,%d,%d,%s>", tname<T>(), BN, NS, FW_B(PLAIN));
     hipLaunchKernelGGL((gemm_ring_kernel<T, BN, NS, PLAIN>), grid, dim3(256), lds, st, a);
     FW_LAUNCH_RET();
 }
@@ -900,6 +910,7 @@ template <bool XT>
 int launch_tr(const GemmArgs& a, hipStream_t st) {
     const size_t lds = 4 * 64 * 256;
     FW_SET_LDS_ONCE(gemm_tr_kernel<XT>, lds);
+    FW_KNAME("gemm_tr_kernel<%s>", FW_B(XT));
     hipLaunchKernelGGL(gemm_tr_kernel<XT>, dim3(fw_cdiv(a.M, 128), fw_cdiv(a.N, 128), a.splitk), dim3(256), lds, st, a);
     FW_LAUNCH_RET();
 }
@@ -1080,6 +1091,7 @@ int launch_stream(const GemmArgs& a, hipStream_t st) {
     int gx = fw_cdiv(strips, 8);
     const int cap = 512 / ny > 0 ? 512 / ny : 1;                    // 256 CUs x 2 workgroups
     if (gx > cap) gx = cap;
+    FW_KNAME("gemm_stream_kernel<%s,%d,%s,%s>", tname<T>(), NCH, FW_B(WT), FW_B(EXT));
     hipLaunchKernelGGL((gemm_stream_kernel<T, NCH, WT, EXT>), dim3(gx, ny), dim3(512), lds, st, a, bnp);
     FW_LAUNCH_RET();
 }
@@ -1103,6 +1115,7 @@ int launch(const GemmArgs& a, hipStream_t st) {
     const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW;
     FW_SET_LDS_ONCE((gemm_kernel<T, BN, XT, WT, GX, GW>), lds);
     dim3 grid(fw_cdiv(a.M, BM), fw_cdiv(a.N, BN), a.splitk);
+    FW_KNAME("gemm_kernel<%s,%d,%s,%s,%s,%s>", tname<T>(), BN, FW_B(XT), FW_B(WT), FW_B(GX), FW_B(GW));
     hipLaunchKernelGGL((gemm_kernel<T, BN, XT, WT, GX, GW>), grid, dim3(256), lds, st, a);
     FW_LAUNCH_RET();
 }
@@ -1140,6 +1153,11 @@ int dispatch_trans(const GemmArgs& a, int xt, int wt, hipStream_t st) {
 // family 0 = gemm_kernel (BN = 64 / 128), 1 = gemm_tr_kernel, 2 = gemm_stream_kernel.
 static thread_local int g_last_variant = 0;
 extern "C" int fw_gemm_last_variant(void) { return g_last_variant; }
+extern "C" int fw_gemm_last_kernel(char* buf, int n) {
+    if (!buf || n <= 0) return -1;
+    snprintf(buf, (size_t)n, "%s", g_last_kernel);
+    return (int)strlen(g_last_kernel);
+}
 
 extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op, const void* W, long ldw,
                        int w_trans, int w_op, void* C, long ldc, int out_f32, int accumulate, int M, int N,

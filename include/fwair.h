@@ -38,6 +38,9 @@ int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op, const voi
 /* Measurement aid: the kernel the calling thread's last fw_gemm was dispatched to, as
  * family * 100000 + BN * 100 + x_trans * 10 + w_trans  (family 0 gemm_kernel, 1 gemm_tr_kernel, 2 gemm_stream_kernel). */
 int fw_gemm_last_variant(void);
+/* Same aid, by name: copies the launched kernel's name into buf (rocprofv3's demangled spelling without spaces and with
+ * "unsigned short" written bf16, e.g. "gemm_ring_kernel<bf16,128,2,true>"); returns its length, -1 on a bad buffer. */
+int fw_gemm_last_kernel(char* buf, int n);
 
 /* split-K without atomics: slice z stores its partial tile at C + z*c_zstride (and xsum + z*xsum_zstride); this sums the slices */
 int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, float* dst2, long off2, long n2,

@@ -32,22 +32,17 @@ def per_kernel(d, counter):
     return acc
 
 
+HOT = re.compile(r'\b(gemm_\w*kernel|attn2?_(?:fwd|bwd)_kernel|dwconv_\w+_kernel|ln_\w+_kernel|leff_\w+_kernel|conv3x3_kernel'
+                 r'|slab_reduce_multi_kernel|adam_kernel|ema_kernel)(<.*>)?\(')
+
+
 def short(name):
-    m = re.search(r'gemm_tr_kernel<(true|false)>', name)
-    if m:
-        return f'gemm_tr_kernel<xT={int(m.group(1) == "true")}>'
-    m = re.search(r'gemm_(stream_)?kernel<([^>]*)>', name)
-    if m:
-        a = [x.strip() for x in m.group(2).split(',')]
-        dt = 'bf16' if a[0] == 'unsigned short' else 'f32'
-        if m.group(1):
-            return f'gemm_stream_kernel<{dt},wT={int(a[2] == "true")}>'
-        return f'gemm_kernel<{dt},BN={a[1]},xT={int(a[2] == "true")},wT={int(a[3] == "true")}>'
-    m = re.search(r'(attn_fwd_kernel|attn_bwd_kernel|dwconv_\w+_kernel|ln_fwd_kernel|ln_bwd_kernel|leff_\w+_kernel|slab_reduce_multi_kernel'
-                  r'|adam_kernel|ema_kernel)(<[^>]*>)?', name)
-    if m:
-        return (m.group(1) + (m.group(2) or '')).replace('unsigned short', 'bf16').replace(' ', '')
-    return None
+    """rocprofv3's demangled kernel name -> the spelling fw_gemm_last_kernel() and bench.py use: template arguments kept, spaces
+    dropped, "unsigned short" -> bf16; None for kernels outside the hot list."""
+    m = HOT.search(name.replace('(anonymous namespace)::', ''))
+    if not m:
+        return None
+    return (m.group(1) + (m.group(2) or '')).replace('unsigned short', 'bf16').replace(' ', '')
 
 
 def main():

@@ -162,7 +162,9 @@ def gemm_profile(engine, batch, reps=8):
             if kw.get(key) is not None:
                 by += M * N * kw[key].element_size()
         variant = ('bf16' if x.dtype == torch.bfloat16 else 'f32', kern)
-        out.append((variant, (M, N, K, sk), cnt, 2.0 * M * N * K, float(by), dt, float(over)))
+        flags = '+'.join([f'{k}={v}' for k, v in scal if k in ('act', 'accumulate', 'alpha', 'x_op', 'w_op', 'rows_per_scale')] +
+                         [k for k, _ in tens if k not in ('x', 'w', 'out')] + [str(kw['out'].dtype).replace('torch.', 'out_')])
+        out.append((variant, (M, N, K, sk, flags), cnt, 2.0 * M * N * K, float(by), dt, float(over)))
         del g, sets, kw, x, w
     agg = {}
     for variant, shape, cnt, fl, by, dt, over in out:
@@ -173,11 +175,11 @@ def gemm_profile(engine, batch, reps=8):
     dump = os.environ.get('FW_GEMM_DUMP')
     if dump:
         with open(dump, 'w') as f:
-            f.write('dtype,kernel,M,N,K,splitk,launches_per_step,us_per_launch,ms_per_step,TFLOPs,GBs,roofline_us\n')
+            f.write('dtype,kernel,M,N,K,splitk,launches_per_step,us_per_launch,ms_per_step,TFLOPs,GBs,roofline_us,epilogue\n')
             for v, sh, cnt, fl, by, dt, _ in sorted(out, key=lambda r: -r[2] * r[5]):
                 roof = max(fl / PEAK_FOR[v[0]], by / PEAK_HBM) * 1e6
                 f.write(f'{v[0]},"{v[1]}",{sh[0]},{sh[1]},{sh[2]},{sh[3]},{cnt},{dt * 1e6:.1f},'
-                        f'{dt * cnt * 1e3:.3f},{fl / dt / 1e12:.1f},{by / dt / 1e9:.0f},{roof:.1f}\n')
+                        f'{dt * cnt * 1e3:.3f},{fl / dt / 1e12:.1f},{by / dt / 1e9:.0f},{roof:.1f},{sh[4]}\n')
     return agg, len(rec)
 
 

@@ -93,6 +93,31 @@ FW_DEV float gelu_grad_f(float x) {
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+// The bf16 instantiations evaluate GELU / GELU' WITHOUT transcendentals: x is clamped to [-4, 4] and Phi(x) - 1/2 = x P(x^2),
+// GELU'(x) - 1/2 = x R(x^2) with degree-7 P, R (tools/fit_gelu_poly.py: weighted minimax fits; |GELU error| <= 5e-5 on [-4, 4] and
+// <= 4e-5 |x| beyond, |GELU' error| <= 3e-4 -- the results are then rounded to bf16, whose half-ulp is 2e-3 |x|).  11 full-rate
+// VALU instructions that pair up as v_pk_fma_f32, against ~14 plus two quarter-rate transcendentals (v_rcp, v_exp) of the erf form:
+// the fc1 / fc2-input-gradient epilogues and the depthwise kernels were bound by exactly this arithmetic.  f32 keeps the erf form.
+FW_DEV float gelu_poly(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
+    const float u = xc * xc;
+    float p = -1.301290697e-09f;
+    p = fmaf(p, u, 1.041962340e-07f); p = fmaf(p, u, -3.657149647e-06f); p = fmaf(p, u, 7.485542814e-05f);
+    p = fmaf(p, u, -1.006494109e-03f); p = fmaf(p, u, 9.505412949e-03f); p = fmaf(p, u, -6.588785358e-02f);
+    p = fmaf(p, u, 3.986733717e-01f);
+    return x * fmaf(xc, p, 0.5f);
+}
+FW_DEV float gelu_grad_poly(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
+    const float u = xc * xc;
+    float r = -1.641741003e-08f;
+    r = fmaf(r, u, 1.213663647e-06f); r = fmaf(r, u, -3.845618281e-05f); r = fmaf(r, u, 6.876052189e-04f);
+    r = fmaf(r, u, -7.687198903e-03f); r = fmaf(r, u, 5.591419208e-02f); r = fmaf(r, u, -2.620297180e-01f);
+    r = fmaf(r, u, 7.967230048e-01f);
+    return fmaf(xc, r, 0.5f);
+}
+template <typename T> FW_DEV float gelu_t(float x) { return sizeof(T) == 2 ? gelu_poly(x) : gelu_f(x); }
+template <typename T> FW_DEV float gelu_grad_t(float x) { return sizeof(T) == 2 ? gelu_grad_poly(x) : gelu_grad_f(x); }
 FW_DEV float lrelu_f(float x, float s) { return x > 0.f ? x : x * s; }
 
 FW_DEV float wave_sum(float v) {

@@ -193,13 +193,13 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
             if (MODE == 0) {
                 stvec4<T>(out + (tok0 + o) * ldo + c0, acc[o]);
 #pragma unroll
-                for (int e = 0; e < E; ++e) acc[o][e] = gelu_f(acc[o][e]);
+                for (int e = 0; e < E; ++e) acc[o][e] = gelu_t<T>(acc[o][e]);
                 stvec4<T>(out2 + (tok0 + o) * ldo + c0, acc[o]);
             } else {
                 float hc[E];
                 rpre[o].unpack(hc);
 #pragma unroll
-                for (int e = 0; e < E; ++e) acc[o][e] *= gelu_grad_f(hc[e]);
+                for (int e = 0; e < E; ++e) acc[o][e] *= gelu_grad_t<T>(hc[e]);
                 stvec4<T>(out + (tok0 + o) * ldo + c0, acc[o]);
             }
         }
@@ -302,13 +302,13 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const T* __restrict__ 
         if (MODE == 0) {
             stvec4<T>(out + (tok0 + o) * ldo + c0, acc[o]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[o][e] = gelu_f(acc[o][e]);
+            for (int e = 0; e < 4; ++e) acc[o][e] = gelu_t<T>(acc[o][e]);
             stvec4<T>(out2 + (tok0 + o) * ldo + c0, acc[o]);
         } else {
             float hc[4];
             rpre[o].unpack(hc);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[o][e] *= gelu_grad_f(hc[e]);
+            for (int e = 0; e < 4; ++e) acc[o][e] *= gelu_grad_t<T>(hc[e]);
             stvec4<T>(out + (tok0 + o) * ldo + c0, acc[o]);
         }
     }

@@ -65,7 +65,7 @@ template <typename T> FW_DEV uint4 apply_gelu16(const uint4& v) {
     float f[TT<T>::E16];
     unpack16<T>(v, f);
 #pragma unroll
-    for (int i = 0; i < TT<T>::E16; ++i) f[i] = gelu_f(f[i]);
+    for (int i = 0; i < TT<T>::E16; ++i) f[i] = gelu_t<T>(f[i]);
     return pack16<T>(f);
 }
 
@@ -102,10 +102,10 @@ FW_DEV void epi_apply(const GemmArgs& a, const f32x4& bias, const uint4& ext, co
         else { x[0] = __uint_as_float(ext.x << 16); x[1] = __uint_as_float(ext.x & 0xffff0000u);
                x[2] = __uint_as_float(ext.y << 16); x[3] = __uint_as_float(ext.y & 0xffff0000u); }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(x[r]);
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_t<T>(x[r]);
     } else if (a.act == 3) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_t<T>(v[r]);
     }
     if (a.rowscale) {
 #pragma unroll
@@ -118,7 +118,7 @@ FW_DEV void epi_apply(const GemmArgs& a, const f32x4& bias, const uint4& ext, co
     }
     if (a.C2) {
         T* c2 = reinterpret_cast<T*>(a.C2) + (long)m * a.ldc2 + n0;
-        const float g0 = gelu_f(v[0]), g1 = gelu_f(v[1]), g2 = gelu_f(v[2]), g3 = gelu_f(v[3]);
+        const float g0 = gelu_t<T>(v[0]), g1 = gelu_t<T>(v[1]), g2 = gelu_t<T>(v[2]), g3 = gelu_t<T>(v[3]);
         if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(c2) = f32x4{g0, g1, g2, g3};
         else *reinterpret_cast<uint2*>(c2) = make_uint2(pack_bf2(g0, g1), pack_bf2(g2, g3));
     }
@@ -605,21 +605,28 @@ FW_DEV void tile_epilogue(const GemmArgs& a, const f32x4 (&acc)[4][WM], int m_bl
             }
         }
     } else {
+        // the row-dependent operand (GELU' input / residual) of the WHOLE wave tile is requested first -- one memory latency per
+        // tile instead of one per 16-row group (fetch 4, wait, apply, fetch 4, ...: four exposed round trips after a 7-step K loop)
+        uint4 ext[WM][4];
+        float rs[WM];
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt) {
             const int m = m_blk + wm0 + mt * 16 + (l & 15);
             const int mc = m < a.M ? m : a.M - 1;
-            const float rs = a.rowscale ? a.rowscale[mc / a.rows_per_scale] : 1.0f;
-            uint4 ext[4];
+            rs[mt] = a.rowscale ? a.rowscale[mc / a.rows_per_scale] : 1.0f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
-                epi_fetch<T>(a, ext[nt], mc, n0 < a.N ? n0 : 0, bz);
+                epi_fetch<T>(a, ext[mt][nt], mc, n0 < a.N ? n0 : 0, bz);
             }
+        }
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+            const int m = m_blk + wm0 + mt * 16 + (l & 15);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
-                if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], ext[nt], acc[nt][mt], m, n0, rs, bz);
+                if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], ext[mt][nt], acc[nt][mt], m, n0, rs[mt], bz);
             }
         }
     }

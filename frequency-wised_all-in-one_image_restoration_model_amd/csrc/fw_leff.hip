@@ -112,7 +112,7 @@ __global__ __launch_bounds__(LTH, 2) void leff_fwd_kernel(LeffArgs a) {
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b1 + hc0 + cl);
                 float hv[4], gv[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { hv[q] = acc[q] + bb[q]; gv[q] = gelu_f(hv[q]); }
+                for (int q = 0; q < 4; ++q) { hv[q] = acc[q] + bb[q]; gv[q] = gelu_poly(hv[q]); }
                 *reinterpret_cast<uint2*>(g1s + p * LDG1 + cl * 2) = inimg ? make_uint2(pack_bf2(gv[0], gv[1]), pack_bf2(gv[2], gv[3])) : make_uint2(0, 0);
                 if (twins && inimg && py >= 1 && py <= LT_Y && px >= 1 && px <= LT_X) {      // centre pixel: this tile owns its h1 / g1
                     const long row = img0 + (long)iy * a.W + ix;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(LTH, 2) void leff_fwd_kernel(LeffArgs a) {
                 const long row = img0 + (long)(y0 + py) * a.W + x0 + px;
 #pragma unroll
                 for (int e0 = 0; e0 < GCH; e0 += 4) {
-                    const float g0 = gelu_f(s[e0]), g1v = gelu_f(s[e0 + 1]), g2v = gelu_f(s[e0 + 2]), g3 = gelu_f(s[e0 + 3]);
+                    const float g0 = gelu_poly(s[e0]), g1v = gelu_poly(s[e0 + 1]), g2v = gelu_poly(s[e0 + 2]), g3 = gelu_poly(s[e0 + 3]);
                     const uint2 hp = make_uint2(pack_bf2(s[e0], s[e0 + 1]), pack_bf2(s[e0 + 2], s[e0 + 3]));
                     const uint2 gp = make_uint2(pack_bf2(g0, g1v), pack_bf2(g2v, g3));
                     *reinterpret_cast<uint2*>(g2s + p * LDG2 + (cg + e0) * 2) = gp;

@@ -18,66 +18,92 @@ template <int G> FW_DEV float group_sum(float v) {
     return v;
 }
 
-template <typename T, int G>
+template <typename T> struct RawV;                         // 4 elements of T kept packed until they are consumed
+template <> struct RawV<float> {
+    f32x4 v;
+    FW_MEM void load(const float* p) { v = *reinterpret_cast<const f32x4*>(p); }
+    FW_MEM void unpack(float* f) const { f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3]; }
+};
+template <> struct RawV<bf16raw> {
+    uint2 v;
+    FW_MEM void load(const bf16raw* p) { v = *reinterpret_cast<const uint2*>(p); }
+    FW_MEM void unpack(float* f) const {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+};
+
+// Both kernels are pure streams (read a row, two group reductions, write a row), i.e. bound by how many bytes a CU keeps in
+// flight: with ONE row per lane group outstanding (the first form of these kernels) a CU had ~40 KB requested at a time and the
+// pass ran at 2.8 TB/s.  Now a lane group owns U rows per step -- all their loads are issued back to back from CLAMPED coordinates
+// (no branch between them), then the rows are reduced and written -- and the per-lane arrays are sized by NV = ceil(C / 4 / G),
+// not by the C = 1024 maximum.  G lanes per row (16 / 32 / 64 by width) so that narrow rows (C = 28, 56) do not idle a wave.
+template <typename T, int G, int NV, int U>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y, long ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                      int C, float eps) {
-    const int gl = threadIdx.x % G;
-    const int row = (int)((blockIdx.x * 256L + threadIdx.x) / G);
-    const bool live = row < rows;
+    constexpr int RPB = 256 / G;
+    const int gl = threadIdx.x % G, gr = threadIdx.x / G;
     const int nv = C >> 2;
-    f32x4 v[NVMAX];
-    float s = 0.f;
+    const long r0 = (long)blockIdx.x * RPB * U;
+    f32x4 v[U][NV];
 #pragma unroll
-    for (int t = 0; t < NVMAX; ++t) {
-        const int c4 = gl + G * t;
-        v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (live && c4 < nv) v[t] = *reinterpret_cast<const f32x4*>(x + (long)row * ldx + c4 * 4);
-        s += v[t][0] + v[t][1] + v[t][2] + v[t][3];
-    }
-    const float mu = group_sum<G>(s) / C;
-    float q = 0.f;
+    for (int u = 0; u < U; ++u) {
+        const long row = r0 + u * RPB + gr;
+        const float* xr = x + (row < rows ? row : rows - 1) * ldx;
 #pragma unroll
-    for (int t = 0; t < NVMAX; ++t) {
-        const int c4 = gl + G * t;
-        if (c4 < nv) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[t][e] - mu; q += d * d; }
+        for (int t = 0; t < NV; ++t) {
+            const int c4 = gl + G * t;
+            v[u][t] = *reinterpret_cast<const f32x4*>(xr + (c4 < nv ? c4 : nv - 1) * 4);
         }
     }
-    const float rs = rsqrtf(group_sum<G>(q) / C + eps);
-    if (!live) return;
-    if (gl == 0) { mean[row] = mu; rstd[row] = rs; }
+    f32x4 gam[NV], bet[NV];
 #pragma unroll
-    for (int t = 0; t < NVMAX; ++t) {
-        const int c4 = gl + G * t;
-        if (c4 < nv) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c4 * 4);
-            float o[4];
+    for (int t = 0; t < NV; ++t) {
+        const int c4 = gl + G * t < nv ? gl + G * t : nv - 1;
+        gam[t] = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
+        bet[t] = *reinterpret_cast<const f32x4*>(beta + c4 * 4);
+    }
+    const float invc = 1.0f / C;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[t][e] - mu) * rs * g[e] + b[e];
-            T* yp = y + (long)row * ldy + c4 * 4;
-            if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
-            else *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+    for (int u = 0; u < U; ++u) {
+        const long row = r0 + u * RPB + gr;
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            if (gl + G * t >= nv) v[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s += v[u][t][0] + v[u][t][1] + v[u][t][2] + v[u][t][3];
+        }
+        const float mu = group_sum<G>(s) * invc;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            if (gl + G * t < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[u][t][e] - mu; q += d * d; }
+            }
+        }
+        const float rs = rsqrtf(group_sum<G>(q) * invc + eps);
+        if (row >= rows) continue;
+        if (gl == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int c4 = gl + G * t;
+            if (c4 < nv) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[u][t][e] - mu) * rs * gam[t][e] + bet[t][e];
+                T* yp = y + row * ldy + c4 * 4;
+                if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
+                else *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
         }
     }
 }
 
-template <typename T> FW_DEV void load4(const T* p, float* f);
-template <> FW_SPEC void load4<float>(const float* p, float* f) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-    f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
-}
-template <> FW_SPEC void load4<bf16raw>(const bf16raw* p, float* f) {
-    const uint2 v = *reinterpret_cast<const uint2*>(p);
-    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-}
-
-// Each block walks rows blockIdx.x*RPB + k*gridDim.x*RPB ...; column partial sums stay in registers.
-template <typename T, int G>
+// Each block walks row groups blockIdx.x, blockIdx.x + gridDim.x, ... of RPB * U rows; column partial sums stay in registers.
+template <typename T, int G, int NV, int U>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres, long lddres,
@@ -87,72 +113,85 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, l
     constexpr int RPB = 256 / G;
     const int gl = threadIdx.x % G, gr = threadIdx.x / G;
     const int nv = C >> 2;
-    f32x4 gam[NVMAX], dg[NVMAX], db[NVMAX];
+    const float invc = 1.0f / C;
+    f32x4 gam[NV], dg[NV], db[NV];
+    bool cok[NV];
 #pragma unroll
-    for (int t = 0; t < NVMAX; ++t) {
+    for (int t = 0; t < NV; ++t) {
         const int c4 = gl + G * t;
-        gam[t] = (c4 < nv) ? *reinterpret_cast<const f32x4*>(gamma + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        cok[t] = c4 < nv;
+        gam[t] = cok[t] ? *reinterpret_cast<const f32x4*>(gamma + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         dg[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (long r0 = (long)blockIdx.x * RPB; r0 < rows; r0 += (long)gridDim.x * RPB) {
-        const long row = r0 + gr;
-        const bool live = row < rows;
-        const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
-        f32x4 xh[NVMAX], g[NVMAX];
-        float s1 = 0.f, s2 = 0.f;
+    for (long r0 = (long)blockIdx.x * RPB * U; r0 < rows; r0 += (long)gridDim.x * RPB * U) {
+        // ---- every load of the U rows first ----
+        f32x4 xv[U][NV], rr[U][NV];
+        RawV<T> dr[U][NV];
+        float mu[U], rs[U];
 #pragma unroll
-        for (int t = 0; t < NVMAX; ++t) {
-            const int c4 = gl + G * t;
-            xh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            g[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (live && c4 < nv) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c4 * 4);
+        for (int u = 0; u < U; ++u) {
+            const long row = r0 + u * RPB + gr;
+            const long rc = row < rows ? row : rows - 1;
+            mu[u] = mean[rc]; rs[u] = rstd[rc];
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                const int cc = (cok[t] ? gl + G * t : nv - 1) * 4;
+                xv[u][t] = *reinterpret_cast<const f32x4*>(x + rc * ldx + cc);
+                dr[u][t].load(dy + rc * lddy + cc);
+                if (dres) rr[u][t] = *reinterpret_cast<const f32x4*>(dres + rc * lddres + cc);
+            }
+        }
+        // ---- then row by row ----
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long row = r0 + u * RPB + gr;
+            const bool live = row < rows;
+            f32x4 xh[NV], g[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
                 float d[4];
-                load4<T>(dy + row * lddy + c4 * 4, d);
+                dr[u][t].unpack(d);
+                const bool ok = live && cok[t];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    xh[t][e] = (xv[e] - mu) * rs;
-                    g[t][e] = d[e] * gam[t][e];
-                    dg[t][e] += d[e] * xh[t][e];
-                    db[t][e] += d[e];
+                    const float de = ok ? d[e] : 0.f;
+                    xh[t][e] = ok ? (xv[u][t][e] - mu[u]) * rs[u] : 0.f;
+                    g[t][e] = de * gam[t][e];
+                    dg[t][e] += de * xh[t][e];
+                    db[t][e] += de;
                     s1 += g[t][e];
                     s2 += g[t][e] * xh[t][e];
                 }
             }
-        }
-        s1 = group_sum<G>(s1) / C;
-        s2 = group_sum<G>(s2) / C;
-        if (live) {
+            s1 = group_sum<G>(s1) * invc;
+            s2 = group_sum<G>(s2) * invc;
+            if (!live) continue;
+            const float sc = (twin && twscale) ? twscale[row / tw_rows_per_scale] : 1.0f;
 #pragma unroll
-            for (int t = 0; t < NVMAX; ++t) {
+            for (int t = 0; t < NV; ++t) {
+                if (!cok[t]) continue;
                 const int c4 = gl + G * t;
-                if (c4 < nv) {
-                    f32x4 o;
+                f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = rs * (g[t][e] - s1 - xh[t][e] * s2);
-                    if (dres) {
-                        const f32x4 rr = *reinterpret_cast<const f32x4*>(dres + row * lddres + c4 * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += rr[e];
-                    }
-                    *reinterpret_cast<f32x4*>(dx + row * lddx + c4 * 4) = o;
-                    if (twin) {                                  // the operand copy the preceding Linear's backward needs: T(dx * DropPath scale)
-                        const float sc = twscale ? twscale[row / tw_rows_per_scale] : 1.0f;
-                        T* tp = twin + row * ldtw + c4 * 4;
-                        if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(tp) = f32x4{o[0] * sc, o[1] * sc, o[2] * sc, o[3] * sc};
-                        else *reinterpret_cast<uint2*>(tp) = make_uint2(pack_bf2(o[0] * sc, o[1] * sc), pack_bf2(o[2] * sc, o[3] * sc));
-                    }
+                for (int e = 0; e < 4; ++e) o[e] = rs[u] * (g[t][e] - s1 - xh[t][e] * s2);
+                if (dres) o += rr[u][t];
+                *reinterpret_cast<f32x4*>(dx + row * lddx + c4 * 4) = o;
+                if (twin) {                                  // the operand copy the preceding Linear's backward needs: T(dx * DropPath scale)
+                    T* tp = twin + row * ldtw + c4 * 4;
+                    if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(tp) = o * sc;
+                    else *reinterpret_cast<uint2*>(tp) = make_uint2(pack_bf2(o[0] * sc, o[1] * sc), pack_bf2(o[2] * sc, o[3] * sc));
                 }
             }
         }
     }
-    // block reduction of the column partials over the RPB row-groups, then one atomic per column
+    // block reduction of the column partials over the RPB row-groups, then one plain store per column
     __shared__ float red[2][1024];
     for (int i = threadIdx.x; i < 2048; i += 256) (&red[0][0])[i] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < NVMAX; ++t) {
+    for (int t = 0; t < NV; ++t) {
         const int c4 = gl + G * t;
         if (c4 < nv) {
 #pragma unroll
@@ -173,28 +212,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, l
     }
 }
 
-template <typename T, int G>
+// rows per lane group and step (U) by the number of 16-byte vectors a lane holds per row (NV): about 4 row-vectors in flight
+template <typename T, int G, int NV, int U>
 int ln_fwd_launch(const float* x, long ldx, const float* g, const float* b, void* y, long ldy, float* mean,
                   float* rstd, int rows, int C, float eps, hipStream_t st) {
-    const int rpb = 256 / G;
-    hipLaunchKernelGGL((ln_fwd_kernel<T, G>), dim3(fw_cdiv(rows, rpb)), dim3(256), 0, st, x, ldx, g, b, (T*)y, ldy,
+    const int rpb = 256 / G * U;
+    hipLaunchKernelGGL((ln_fwd_kernel<T, G, NV, U>), dim3(fw_cdiv(rows, rpb)), dim3(256), 0, st, x, ldx, g, b, (T*)y, ldy,
                        mean, rstd, rows, C, eps);
     FW_LAUNCH_RET();
 }
-static inline int ln_group(int C) { return C <= 64 ? 16 : (C <= 128 ? 32 : 64); }
+static inline int ln_group(int C) { return C <= 32 ? 8 : (C <= 64 ? 16 : (C <= 128 ? 32 : 64)); }
+static inline int ln_rows_per_step(int C) { return C <= 256 ? 4 : (C <= 512 ? 2 : 1); }
 static inline int ln_bwd_grid(int rows, int C) {
     static const int cap = getenv("FW_LN_BWD_GRID") ? atoi(getenv("FW_LN_BWD_GRID")) : 1024;
-    return min(fw_cdiv(rows, 256 / ln_group(C)), cap);
+    return min(fw_cdiv(rows, 256 / ln_group(C) * ln_rows_per_step(C)), cap);
 }
 
-template <typename T, int G>
+template <typename T, int G, int NV, int U>
 int ln_bwd_launch(const void* dy, long lddy, const float* x, long ldx, const float* g, const float* mean,
                   const float* rstd, const float* dres, long lddres, float* dx, long lddx, float* partial, long pstride,
                   int rows, int C, void* twin, long ldtw, const float* twscale, int twrps, hipStream_t st) {
-    hipLaunchKernelGGL((ln_bwd_kernel<T, G>), dim3(ln_bwd_grid(rows, C)), dim3(256), 0, st, (const T*)dy, lddy, x, ldx, g, mean, rstd,
+    hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV, U>), dim3(ln_bwd_grid(rows, C)), dim3(256), 0, st, (const T*)dy, lddy, x, ldx, g, mean, rstd,
                        dres, lddres, dx, lddx, partial, pstride, rows, C, (T*)twin, ldtw, twscale, twrps);
     FW_LAUNCH_RET();
 }
+
+// (G, NV, U) by row width
+#define LN_DISPATCH(FN, T, ...)                                    \
+    (C <= 32 ? FN<T, 8, 1, 4>(__VA_ARGS__)                         \
+     : C <= 64 ? FN<T, 16, 1, 4>(__VA_ARGS__)                      \
+     : C <= 128 ? FN<T, 32, 1, 4>(__VA_ARGS__)                     \
+     : C <= 256 ? FN<T, 64, 1, 4>(__VA_ARGS__)                     \
+     : C <= 512 ? FN<T, 64, 2, 2>(__VA_ARGS__)                     \
+                : FN<T, 64, 4, 1>(__VA_ARGS__))
 
 }  // namespace
 
@@ -203,10 +253,7 @@ extern "C" int fw_layernorm_fwd(int dtype, const float* x, long ldx, const float
     FW_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0);
     FW_CHECK_ARG(x && gamma && beta && y && mean && rstd);
     hipStream_t st = (hipStream_t)stream;
-#define LN_F(T)                                                                                                 \
-    (C <= 64 ? ln_fwd_launch<T, 16>(x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C, eps, st)                  \
-             : C <= 128 ? ln_fwd_launch<T, 32>(x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C, eps, st)       \
-                        : ln_fwd_launch<T, 64>(x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C, eps, st))
+#define LN_F(T) LN_DISPATCH(ln_fwd_launch, T, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C, eps, st)
     return dtype == FW_DT_BF16 ? LN_F(bf16raw) : LN_F(float);
 #undef LN_F
 }
@@ -227,13 +274,9 @@ extern "C" int fw_layernorm_bwd2(int dtype, const void* dy, long lddy, const flo
     FW_CHECK_ARG(!twin || (ldtw % 4 == 0 && (!twscale || tw_rows_per_scale > 0)));
     hipStream_t st = (hipStream_t)stream;
     const long pstride = 2L * C;
-#define LN_B(T)                                                                                                      \
-    (C <= 64 ? ln_bwd_launch<T, 16>(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, partial, pstride, rows, \
-                                    C, twin, ldtw, twscale, tw_rows_per_scale, st)                                                                           \
-             : C <= 128 ? ln_bwd_launch<T, 32>(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, partial,  \
-                                               pstride, rows, C, twin, ldtw, twscale, tw_rows_per_scale, st)                                                 \
-                        : ln_bwd_launch<T, 64>(dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, partial,  \
-                                               pstride, rows, C, twin, ldtw, twscale, tw_rows_per_scale, st))
+#define LN_B(T)                                                                                                          \
+    LN_DISPATCH(ln_bwd_launch, T, dy, lddy, x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, partial, pstride, rows, C, twin, \
+                ldtw, twscale, tw_rows_per_scale, st)
     const int rc = dtype == FW_DT_BF16 ? LN_B(bf16raw) : LN_B(float);
 #undef LN_B
     if (rc || !dgamma) return rc;                  // dgamma == dbeta == null: the caller folds the partials later (fw_slab_reduce_multi)

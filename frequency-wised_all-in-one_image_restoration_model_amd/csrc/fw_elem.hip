@@ -88,6 +88,35 @@ __global__ void permute3_kernel(const TI* __restrict__ in, TO* __restrict__ out,
     }
 }
 
+// Many small f32 -> (f32 | bf16) re-layouts in ONE launch: the per-step operand copies of parameters whose stored layout no GEMM /
+// stencil kernel reads directly (depthwise taps -> tap-major, k4s2 / k2s2 convolution weights -> [Cout][K], rows that are not 16-byte
+// aligned in bf16).  ~170 launches of 5-8 us each per training step otherwise.
+// tab: [num][10] int64 = src, dst, d0, d1, d2, s0, s1, s2, out_bf16, unused;  prefix: [num + 1] int64 block offsets; a block owns
+// 1024 consecutive source elements of its entry:  dst[a*s0 + b*s1 + c*s2] = src[(a*d1 + b)*d2 + c].
+__global__ __launch_bounds__(256) void permute3_multi_kernel(const long long* __restrict__ tab, const long long* __restrict__ prefix, int num) {
+    int lo = 0, hi = num;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= (long long)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const long long* t = tab + (long)lo * 10;
+    const float* src = reinterpret_cast<const float*>(t[0]);
+    const int d1 = (int)t[3], d2 = (int)t[4];
+    const long n = t[2] * t[3] * t[4], s0 = t[5], s1 = t[6], s2 = t[7];
+    const bool bf = t[8] != 0;
+    const long base = ((long long)blockIdx.x - prefix[lo]) * 1024;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long i = base + r * 256 + threadIdx.x;
+        if (i >= n) break;
+        const int c = (int)(i % d2); const long q = i / d2; const int b = (int)(q % d1); const long a = q / d1;
+        const long o = a * s0 + b * s1 + c * s2;
+        const float v = src[i];
+        if (bf) TT<bf16raw>::st(reinterpret_cast<bf16raw*>(t[1]) + o, v);
+        else reinterpret_cast<float*>(t[1])[o] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LeFF depthwise 3x3 (net/utils/leff.py:104-111).  Pre- and post-activation tensors are both kept
 // (h = pre, g = GELU(h)) so no erf is ever recomputed per tap:
@@ -1108,6 +1137,13 @@ extern "C" int fw_slab_reduce(const float* slab, int nz, long n, long zstride, f
 extern "C" int fw_slab_reduce_multi(const void* tab, const void* prefix, int num, long total_blocks, void* stream) {
     FW_CHECK_ARG(tab && prefix && num > 0 && total_blocks > 0 && total_blocks < (1L << 31));
     hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, ST, (const long long*)tab, (const long long*)prefix, num);
+    FW_LAUNCH_RET();
+}
+// One launch for `num` re-layouts; tab / prefix are DEVICE arrays as permute3_multi_kernel documents (entry e owns
+// ceil(d0*d1*d2 / 1024) blocks).
+extern "C" int fw_permute3_multi(const void* tab, const void* prefix, int num, long total_blocks, void* stream) {
+    FW_CHECK_ARG(tab && prefix && num > 0 && total_blocks > 0 && total_blocks < (1L << 31));
+    hipLaunchKernelGGL(permute3_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, ST, (const long long*)tab, (const long long*)prefix, num);
     FW_LAUNCH_RET();
 }
 extern "C" int fw_fill(float* p, long n, float v, void* stream) {

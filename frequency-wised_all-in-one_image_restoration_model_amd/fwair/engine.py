@@ -222,6 +222,7 @@ class TrainEngine:
         moco = net.E.E
         enc_q = ordered_parameters(moco.encoder_q)
         enc_k = ordered_parameters(moco.encoder_k)
+        self._k_ids = {id(p) for p in enc_k}
         qids = {id(q) for q in enc_q}
         rest = [p for p in ordered_parameters(net) if p.requires_grad and id(p) not in qids]
         self.trainable = enc_q + rest                      # query encoder first: its slice mirrors the key encoder
@@ -330,10 +331,13 @@ class TrainEngine:
             call('fw_cast_flat', 1, self.flat_p, self.shadow_p, self.n)
             call('fw_cast_flat', 1, self.flat_k, self.shadow_k, self.n_enc)
         Fn.config.shadow_epoch += 1
+        Fn.refresh_shadows('all')         # the captured forward reads these buffers without re-deriving them (the graph's own refresh
+                                          # follows its Adam step)
 
     def _ema(self):
         call('fw_ema', 1 if self.shadow_k is not None else 0, self.flat_k, self.flat_p, self.shadow_k, self.n_enc, self.net.E.E.m)
         Fn.config.shadow_epoch += 1
+        Fn.refresh_shadows('key', only_ids=self._k_ids, restamp_others=True)      # only the key encoder's parameters changed
 
     def _freq_term(self, restored, clean):
         """weight * L1(decompose(restored), decompose(clean)), pre-scaled like the other loss gradients (differentiable module)."""
@@ -423,6 +427,7 @@ class TrainEngine:
             call('fw_adam', sh, self.flat_p[ne:], self.flat_g[ne:], self.m[ne:], self.v[ne:],
                  self.shadow_p[ne:] if self.shadow_p is not None else None, self.n - ne, self.hyper_rest, self.betas[0], self.betas[1], self.eps)
         Fn.config.shadow_epoch += 1
+        Fn.refresh_shadows('all')                            # re-laid-out operand copies of the new weights, one launch
 
     # ---- phase 1 (train.py:82-86): encoder only, contrastive loss only -------------------------------------------------
     def _fwd_bwd_p1(self, xq, xk):

@@ -60,22 +60,23 @@ def shadow(param, kind='plain'):
     stamp = (param._version, config.shadow_epoch, p.data_ptr())
     if ent is not None and key in ent and ent[key][0] == stamp:
         return ent[key][1]
+    recipe = None                                   # (src f32 view, (d0, d1, d2), output strides): out[a*s0 + b*s1 + c*s2] = src[a][b][c]
     if kind == 'plain':
         n, k = p.shape[0], p[0].numel()
         out = act_empty(n, k, dtype, p.device)
-        call('fw_cast_rows', dt(dtype), p.reshape(n, k), k, out, out.stride(0), n, k, None, 1)
+        recipe = (p.reshape(n, k), (1, n, k), (0, out.stride(0), 1))
     elif kind == 'conv4':
         co, ci = p.shape[0], p.shape[1]
         out = torch.empty((co, 16 * ci), dtype=dtype, device=p.device)
-        ops.permute3(p.contiguous(), out, (co, ci, 16), (16 * ci, 1, ci))
+        recipe = (p.contiguous(), (co, ci, 16), (16 * ci, 1, ci))
     elif kind == 'dw9':
         c = p.shape[0]
         out = torch.empty((9, c), dtype=torch.float32, device=p.device)       # depthwise 3x3 taps, tap-major (always f32)
-        ops.permute3(p.reshape(c, 9), out, (1, c, 9), (0, 1, c))
+        recipe = (p.reshape(c, 9), (1, c, 9), (0, 1, c))
     elif kind == 'convT2':
         ci, co = p.shape[0], p.shape[1]
         out = torch.empty((4 * co, ci), dtype=dtype, device=p.device)
-        ops.permute3(p.contiguous(), out, (ci, co, 4), (1, ci, co * ci))
+        recipe = (p.contiguous(), (ci, co, 4), (1, ci, co * ci))
     elif kind in ('leff1', 'leff2'):
         # operand panels of the fused LeFF kernel (fw_leff_fwd): linear1 [4C][roundup(C, 32)] with zero-padded K;
         # linear2 [roundup(C, 16) + 1][4C] with zero rows (one spare row: the last chunk's fragment reads run 16 elements on)
@@ -85,12 +86,61 @@ def shadow(param, kind='plain'):
         call('fw_cast_rows', 1, p, k, out, cols, n, k, None, 1)
     else:
         raise ValueError(kind)
+    if recipe is not None:
+        src, dims, strides = recipe
+        assert src.data_ptr() == p.data_ptr() and src.is_contiguous(), 'shadow sources must alias the parameter (refresh_shadows re-reads them)'
+        ops.permute3(src, out, dims, strides)
     if ent is None:
         ent = {}
         pid = id(param)
         _shadow[pid] = (weakref.ref(param, lambda _r, pid=pid: _shadow.pop(pid, None)), ent)
-    ent[key] = (stamp, out)
+    ent[key] = (stamp, out, recipe)
     return out
+
+
+_refresh_tables = {}          # which -> (signature, device table, device prefix, num, total blocks)
+
+
+def refresh_shadows(which='all', only_ids=None, restamp_others=False):
+    """Engine hook: the parameters were just rewritten in place (fused Adam / EMA kernels) and config.shadow_epoch bumped.  Re-derive
+    EVERY cached re-laid-out operand copy (depthwise taps, convolution weights, unaligned bf16 rows: ~170 per model) with ONE
+    fw_permute3_multi launch into the buffers they already live in, and mark them fresh -- instead of one 5-8 us launch each when the
+    next forward asks for them.  only_ids: restrict to the parameters with these ids (the key encoder after its EMA update);
+    restamp_others: the remaining entries are known to be unchanged and are marked fresh without a launch.
+    The table of a set is built on first use OUTSIDE stream capture; inside a capture an unseen set is left to the per-entry path."""
+    items, stamps = [], []
+    for pid, (ref, ent) in _shadow.items():
+        param = ref()
+        if param is None:
+            continue
+        mine = only_ids is None or pid in only_ids
+        for key, (stamp, out, recipe) in ent.items():
+            if recipe is None or not (mine or restamp_others):
+                continue
+            fresh = (param._version, config.shadow_epoch, param.data_ptr())
+            if fresh[2] != recipe[0].data_ptr():
+                continue                                             # the parameter moved (e.g. .to(device)): let shadow() rebuild it
+            stamps.append((ent, key, fresh, out, recipe))
+            if mine:
+                src, dims, strides = recipe
+                items.append((src.data_ptr(), out.data_ptr(), dims[0], dims[1], dims[2], strides[0], strides[1], strides[2],
+                              int(out.dtype == torch.bfloat16), 0))
+    if items:
+        sig = tuple(items)
+        cached = _refresh_tables.get(which)
+        if cached is None or cached[0] != sig:
+            if torch.cuda.is_current_stream_capturing():
+                return                                               # no host -> device table upload inside a capture
+            offs, total = [0], 0
+            for it in items:
+                total += (it[2] * it[3] * it[4] + 1023) // 1024
+                offs.append(total)
+            dev = stamps[0][3].device
+            cached = (sig, torch.tensor(items, dtype=torch.int64).to(dev), torch.tensor(offs, dtype=torch.int64).to(dev), len(items), total)
+            _refresh_tables[which] = cached
+        call('fw_permute3_multi', cached[1], cached[2], cached[3], cached[4])
+    for ent, key, fresh, out, recipe in stamps:
+        ent[key] = (fresh, out, recipe)
 
 
 def _zeros(shape, device):

@@ -124,6 +124,11 @@ int fw_add_rows(int dtype, const void* src, long lds_, void* dst, long ldd, long
 int fw_cast_flat(int dtype, const float* src, void* dst, long n, void* stream);
 int fw_permute3(int in_dtype, int out_dtype, const void* in, void* out, int d0, int d1, int d2, long s0, long s1, long s2,
                 int accumulate, void* stream);
+/* `num` re-layouts of the fw_permute3 kind (f32 source) in one launch: the per-step operand copies of parameters (functional.shadow:
+ * depthwise taps, k4s2 / k2s2 convolution weights, bf16 rows that are not 16-byte aligned).  tab: device int64 [num][10] =
+ * {src, dst, d0, d1, d2, s0, s1, s2, out_is_bf16, 0}; prefix: device int64 [num + 1] block offsets, entry e owning
+ * ceil(d0*d1*d2 / 1024) blocks. */
+int fw_permute3_multi(const void* tab, const void* prefix, int num, long total_blocks, void* stream);
 int fw_fill(float* p, long n, float v, void* stream);
 /* LeakyReLU on a contiguous f32 vector -> T, and its backward (encoder_Uformer.py:953-957 head MLPs) */
 int fw_lrelu_fwd(int dtype, const float* x, void* y, long n, float slope, void* stream);

@@ -1197,6 +1197,328 @@ __global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
     for (int idx = threadIdx.x; idx < 225; idx += NTH) atomicAdd(dst + idx * a.heads + h, fold[idx]);
 }
 
+// =====================================================================================================
+// v2 scheme for INTER-band attention (mode 1, L = 3: the queries of band lq over the 2 x 64 keys of the other two bands,
+// encoder_Uformer.py inter-frequency blocks; no frequency selection there).  Same structure as attn2_*: a workgroup walks a
+// contiguous range of windows of one (head, query band); the 225 biases of BOTH (lq, lk) tables sit in LDS and each lane's 2 x 16
+// of them in registers; the five (fwd) / six (bwd) tiles of window w + 1 are requested before window w is computed and stored;
+// barriers are LDS-only.  The v1 kernel walked the two key bands one after the other through ONE K / V buffer -- per window two
+// exposed load round trips, plus a global read of O and dO for D_i that the joint form gets from P and dP in registers.
+// =====================================================================================================
+template <typename T, int D> struct Smem2X {
+    using G = Geo<T, D>;
+    static constexpr int LDPK = 128 * G::SZ + 16;                           // row stride of a [64 queries][2 x 64 keys] tile
+    static constexpr int PB = 64 * LDPK;
+    static constexpr int OFF_T = 2048;                                      // float bins[2][256] in front
+    static constexpr int RQ = PB > G::TILE_D ? PB : G::TILE_D;              // fwd: Q -> P
+    static constexpr int FWD_BYTES = OFF_T + RQ + 4 * G::TILE_D;            // | Q / P | K0 K1 (O staging) | V0 V1 |
+    static constexpr int BWD_BYTES = OFF_T + 8 * G::TILE_D + PB;            // | Q dO K0 K1 V0 V1 | X = P / dS | Y0 Y1 staging |
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(NTH, 1) void attn2x_fwd_kernel(AttnArgs a) {
+    using G = Geo<T, D>;
+    using S = Smem2X<T, D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bins = reinterpret_cast<float*>(smem);
+    char* rA = smem + S::OFF_T; char* rK = rA + S::RQ; char* rV = rK + 2 * G::TILE_D;
+    const int l = lane_id(), w = wave_id();
+    const int nWx = a.W / 8, nWy = a.H / 8, nW = nWx * nWy;
+    const int h = blockIdx.y, lq = blockIdx.z;
+    const int i = w * 16 + (l & 15);
+    const int per = (a.nwin + gridDim.x - 1) / gridDim.x;
+    const int win_begin = blockIdx.x * per, win_end = min(a.nwin, win_begin + per);
+    if (win_begin >= win_end) return;
+    const int lk[2] = {other_band(lq, 0), other_band(lq, 1)};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const float* tb = a.bias + (size_t)(lq * a.L + lk[kt]) * 225 * a.heads + h;
+        for (int idx = threadIdx.x; idx < 225; idx += NTH) bins[kt * 256 + idx] = tb[(size_t)idx * a.heads];
+    }
+    TileLoad<T, D> tq, tk[2], tv[2];
+    auto issue = [&](int win) {
+        const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
+        tq.issue(a.q, a.ld, lq * a.B + b, wy, wx, a.H, a.W, a.shift, h * D);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            tk[kt].issue(a.k, a.ld, lk[kt] * a.B + b, wy, wx, a.H, a.W, a.shift, h * D);
+            tv[kt].issue(a.v, a.ld, lk[kt] * a.B + b, wy, wx, a.H, a.W, a.shift, h * D);
+        }
+    };
+    issue(win_begin);
+    lds_barrier();                          // biases staged
+    BiasRegs br[2];
+    br[0].init(bins, i, a.shift);
+    br[1].init(bins + 256, i, a.shift);
+    for (int win = win_begin; win < win_end; ++win) {
+        const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
+        const bool last_y = wy == nWy - 1, last_x = wx == nWx - 1;
+        const int nq = lq * a.B + b;
+        const size_t item = ((size_t)win * a.L + lq) * a.heads + h;
+        lds_barrier();                    // the previous window's readers are done
+        tq.commit(rA);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) { tk[kt].commit(rK + kt * G::TILE_D); tv[kt].commit(rV + kt * G::TILE_D); }
+        lds_barrier();
+        if (win + 1 < win_end) issue(win + 1);
+        f32x4 p[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) p[kt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < G::KC; ++c) {
+            const uint4 bq = frag_kc(rA, G::LDR, w * 16, c);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) mma_chunk<T>(p[kt][m], frag_kc(rK + kt * G::TILE_D, G::LDR, m * 16, c), bq);
+        }
+        {
+            float mx = -3.0e38f;
+            const unsigned msk = br[0].mask(last_y, last_x);          // the seam flags depend on (i, j) only: the same for both key bands
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sc = p[kt][jt][r] * a.scale + br[kt].get(jt, r, msk);
+                        p[kt][jt][r] = sc;
+                        mx = fmaxf(mx, sc);
+                    }
+            mx = col_reduce_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float e = __expf(p[kt][jt][r] - mx); p[kt][jt][r] = e; sum += e; }
+            sum = col_reduce_sum(sum);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) p[kt][jt] *= inv;
+            if ((l >> 4) == 0) a.lse[item * 64 + i] = mx + __logf(sum);
+        }
+        lds_barrier();                    // Q / K tiles are dead from here on
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) store_acc_T<T>(rA, S::LDPK, kt * 64 + jt * 16, w * 16, p[kt][jt]);
+        wave_fence();
+        f32x4 o[G::DT];
+#pragma unroll
+        for (int m = 0; m < G::DT; ++m) o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int c = 0; c < G::JC; ++c) {
+                const uint4 bp = frag_kc(rA, S::LDPK, w * 16, kt * G::JC + c);
+#pragma unroll
+                for (int m = 0; m < G::DT; ++m) mma_chunk<T>(o[m], frag_km<T>(rV + kt * G::TILE_D, G::LDR, m * 16, c), bp);
+            }
+#pragma unroll
+        for (int m = 0; m < G::DT; ++m) store_acc_T<T>(rK, G::LDR, m * 16, w * 16, o[m]);
+        wave_fence();
+        store_rows16<T, D>(rK, a.out, a.ldo, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+    }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(NTH, 1) void attn2x_bwd_kernel(AttnArgs a) {
+    using G = Geo<T, D>;
+    using S = Smem2X<T, D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bins = reinterpret_cast<float*>(smem);
+    char* sQ = smem + S::OFF_T; char* sDO = sQ + G::TILE_D; char* sK = sDO + G::TILE_D; char* sV = sK + 2 * G::TILE_D;
+    char* sX = sV + 2 * G::TILE_D; char* sY = sX + S::PB;
+    const int l = lane_id(), w = wave_id();
+    const int nWx = a.W / 8, nWy = a.H / 8, nW = nWx * nWy;
+    const int h = blockIdx.y, lq = blockIdx.z;
+    const int i = w * 16 + (l & 15);
+    const int per = (a.nwin + gridDim.x - 1) / gridDim.x;
+    const int win_begin = blockIdx.x * per, win_end = min(a.nwin, win_begin + per);
+    if (win_begin >= win_end) return;
+    const int lk[2] = {other_band(lq, 0), other_band(lq, 1)};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const float* tb = a.bias + (size_t)(lq * a.L + lk[kt]) * 225 * a.heads + h;
+        for (int idx = threadIdx.x; idx < 225; idx += NTH) bins[kt * 256 + idx] = tb[(size_t)idx * a.heads];
+    }
+    f32x4 dbacc[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) dbacc[kt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    TileLoad<T, D> tq, tdo, tk[2], tv[2];
+    auto issue = [&](int win) {
+        const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
+        tq.issue(a.q, a.ld, lq * a.B + b, wy, wx, a.H, a.W, a.shift, h * D);
+        tdo.issue(a.dout, a.lddo, lq * a.B + b, wy, wx, a.H, a.W, a.shift, h * D);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            tk[kt].issue(a.k, a.ld, lk[kt] * a.B + b, wy, wx, a.H, a.W, a.shift, h * D);
+            tv[kt].issue(a.v, a.ld, lk[kt] * a.B + b, wy, wx, a.H, a.W, a.shift, h * D);
+        }
+    };
+    issue(win_begin);
+    lds_barrier();                          // biases staged
+    BiasRegs br[2];
+    br[0].init(bins, i, a.shift);
+    br[1].init(bins + 256, i, a.shift);
+    float lse_next = a.lse[(((size_t)win_begin * a.L + lq) * a.heads + h) * 64 + i];
+    for (int win = win_begin; win < win_end; ++win) {
+        const int b = win / nW, wi = win % nW, wy = wi / nWx, wx = wi % nWx;
+        const bool last_y = wy == nWy - 1, last_x = wx == nWx - 1;
+        const int nq = lq * a.B + b;
+        const float lse = lse_next;
+        lds_barrier();                    // every wave is past its last read of the previous window's tiles / staging
+        tq.commit(sQ); tdo.commit(sDO);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) { tk[kt].commit(sK + kt * G::TILE_D); tv[kt].commit(sV + kt * G::TILE_D); }
+        lds_barrier();
+        if (win + 1 < win_end) {
+            issue(win + 1);
+            lse_next = a.lse[(((size_t)(win + 1) * a.L + lq) * a.heads + h) * 64 + i];
+        }
+        // P^T[j][i] = exp(scale K Q^T + bias + mask - lse_i), dP^T[j][i] = V dO^T -- own columns i, both key bands
+        f32x4 P[2][4], dP[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) { P[kt][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dP[kt][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < G::KC; ++c) {
+            const uint4 bq = frag_kc(sQ, G::LDR, w * 16, c), bd = frag_kc(sDO, G::LDR, w * 16, c);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    mma_chunk<T>(P[kt][m], frag_kc(sK + kt * G::TILE_D, G::LDR, m * 16, c), bq);
+                    mma_chunk<T>(dP[kt][m], frag_kc(sV + kt * G::TILE_D, G::LDR, m * 16, c), bd);
+                }
+        }
+        const unsigned msk = br[0].mask(last_y, last_x);
+        float sd = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __expf(P[kt][jt][r] * a.scale + br[kt].get(jt, r, msk) - lse);
+                    P[kt][jt][r] = pv;
+                    sd += pv * dP[kt][jt][r];
+                }
+                store_acc_T<T>(sX, S::LDPK, kt * 64 + jt * 16, w * 16, P[kt][jt]);      // P [i][j], own rows i
+            }
+        lds_barrier();
+        {   // dV_kt^T[d][j] = sum_i dO[i][d] P[i][j], own columns j of each key band
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x4 dv[G::DT];
+#pragma unroll
+                for (int m = 0; m < G::DT; ++m) dv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < G::JC; ++c) {
+                    const uint4 bn = frag_km<T>(sX, S::LDPK, kt * 64 + w * 16, c);
+#pragma unroll
+                    for (int m = 0; m < G::DT; ++m) mma_chunk<T>(dv[m], frag_km<T>(sDO, G::LDR, m * 16, c), bn);
+                }
+#pragma unroll
+                for (int m = 0; m < G::DT; ++m) store_acc_T<T>(sY + kt * G::TILE_D, G::LDR, m * 16, w * 16, dv[m]);
+            }
+            wave_fence();
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                char* dvp = kt_slot(lq, lk[kt]) == 1 ? a.dv2 : a.dv;
+                store_rows16<T, D>(sY + kt * G::TILE_D, dvp, a.ldd, lk[kt] * a.B + b, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+            }
+        }
+        // D_i = sum_j P dP over both bands;  dS = P o (dP - D_i)
+        {
+            const float di = col_reduce_sum(sd);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dP[kt][jt][r] = P[kt][jt][r] * (dP[kt][jt][r] - di);
+                    dbacc[kt][jt] += dP[kt][jt];
+                }
+        }
+        lds_barrier();                    // every wave is done reading P (sX) and its dV staging rows (sY)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) store_acc_T<T>(sX, S::LDPK, kt * 64 + jt * 16, w * 16, dP[kt][jt]);
+        lds_barrier();
+        // dQ^T[d][i] = sum_kt sum_j K_kt[j][d] dS[i][j] (own i);  dK_kt^T[d][j] = sum_i Q[i][d] dS[i][j] (own j)
+        f32x4 dq[G::DT], dk[2][G::DT];
+#pragma unroll
+        for (int m = 0; m < G::DT; ++m) { dq[m] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[0][m] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[1][m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int c = 0; c < G::JC; ++c) {
+                const uint4 bx = frag_kc(sX, S::LDPK, w * 16, kt * G::JC + c), by = frag_km<T>(sX, S::LDPK, kt * 64 + w * 16, c);
+#pragma unroll
+                for (int m = 0; m < G::DT; ++m) {
+                    mma_chunk<T>(dq[m], frag_km<T>(sK + kt * G::TILE_D, G::LDR, m * 16, c), bx);
+                    mma_chunk<T>(dk[kt][m], frag_km<T>(sQ, G::LDR, m * 16, c), by);
+                }
+            }
+        // own rows only: dK_kt -> sY tiles (rows j), dQ -> sV tile 0 (rows i; V is dead since dP was formed)
+#pragma unroll
+        for (int m = 0; m < G::DT; ++m) {
+            store_acc_T<T>(sY, G::LDR, m * 16, w * 16, dk[0][m] * a.scale);
+            store_acc_T<T>(sY + G::TILE_D, G::LDR, m * 16, w * 16, dk[1][m] * a.scale);
+            store_acc_T<T>(sV, G::LDR, m * 16, w * 16, dq[m] * a.scale);
+        }
+        wave_fence();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            char* dkp = kt_slot(lq, lk[kt]) == 1 ? a.dk2 : a.dk;
+            store_rows16<T, D>(sY + kt * G::TILE_D, dkp, a.ldd, lk[kt] * a.B + b, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+        }
+        store_rows16<T, D>(sV, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+    }
+    float* fold = reinterpret_cast<float*>(smem + S::OFF_T);          // tiles are dead: fold the (i, j) pairs into the 225 relative positions
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        lds_barrier();
+        for (int idx = threadIdx.x; idx < 225; idx += NTH) fold[idx] = 0.f;
+        lds_barrier();
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + ((l >> 4) << 2) + r;
+                atomicAdd(&fold[((i >> 3) - (j >> 3) + 7) * 15 + (i & 7) - (j & 7) + 7], dbacc[kt][jt][r]);
+            }
+        lds_barrier();
+        float* dst = a.dbias + (size_t)(lq * a.L + lk[kt]) * 225 * a.heads;
+        for (int idx = threadIdx.x; idx < 225; idx += NTH) atomicAdd(dst + idx * a.heads + h, fold[idx]);
+    }
+}
+
+template <typename T, int D>
+int x2_launch(bool bwd, const AttnArgs& a, hipStream_t st) {
+    using S = Smem2X<T, D>;
+    const int bytes = bwd ? S::BWD_BYTES : S::FWD_BYTES;
+    if (bwd) { FW_SET_LDS_ONCE((attn2x_bwd_kernel<T, D>), S::BWD_BYTES); } else { FW_SET_LDS_ONCE((attn2x_fwd_kernel<T, D>), S::FWD_BYTES); }
+    const int per_cu = 2 * bytes <= 160 * 1024 ? 2 : 1;
+    int chunks = (256 * per_cu) / (a.heads * a.L);
+    if (chunks < 1) chunks = 1;
+    if (chunks > a.nwin) chunks = a.nwin;
+    if (bwd) hipLaunchKernelGGL((attn2x_bwd_kernel<T, D>), dim3(chunks, a.heads, a.L), dim3(NTH), bytes, st, a);
+    else hipLaunchKernelGGL((attn2x_fwd_kernel<T, D>), dim3(chunks, a.heads, a.L), dim3(NTH), bytes, st, a);
+    FW_LAUNCH_RET();
+}
+
 template <typename T, int D, int LFS>
 int fwd2_launch(const AttnArgs& a, hipStream_t st) {
     using S = Smem2<T, D, LFS>;
@@ -1250,6 +1572,7 @@ int dispatch(bool bwd, int D, int nkt, int lfs, const AttnArgs& a, hipStream_t s
         return bwd ? bwd2_launch<T, DD, FF>(a, st) : fwd2_launch<T, DD, FF>(a, st);
     FW_ATT2(56, 0) FW_ATT2(56, 1) FW_ATT2(56, 2) FW_ATT2(28, 0) FW_ATT2(64, 0)
 #undef FW_ATT2
+    if (v2 && D == 28 && nkt == 2 && a.mode == 1 && a.L == 3 && lfs == 0) return x2_launch<T, 28>(bwd, a, st);
 #define FW_ATT(DD, KK, FF)                                                                     \
     if (D == DD && nkt == KK && lfs == FF)                                                     \
         return bwd ? bwd_launch<T, DD, KK, FF>(a, st) : fwd_launch<T, DD, KK, FF>(a, st);

@@ -605,28 +605,37 @@ FW_DEV void tile_epilogue(const GemmArgs& a, const f32x4 (&acc)[4][WM], int m_bl
             }
         }
     } else {
-        // the row-dependent operand (GELU' input / residual) of the WHOLE wave tile is requested first -- one memory latency per
-        // tile instead of one per 16-row group (fetch 4, wait, apply, fetch 4, ...: four exposed round trips after a 7-step K loop)
-        uint4 ext[WM][4];
-        float rs[WM];
-#pragma unroll
-        for (int mt = 0; mt < WM; ++mt) {
+        // the row-dependent operand (GELU' input / residual) of 16-row group mt + 1 is requested before group mt is applied and
+        // stored: one exposed memory latency per tile instead of one per group.  (Requesting the whole wave tile up front -- 16
+        // loads, 64 registers -- measured SLOWER than group-by-group: 135 -> 145 us at 16384 x 1792 x 448.)
+        auto fetch = [&](uint4 (&ext)[4], int mt) {
             const int m = m_blk + wm0 + mt * 16 + (l & 15);
             const int mc = m < a.M ? m : a.M - 1;
-            rs[mt] = a.rowscale ? a.rowscale[mc / a.rows_per_scale] : 1.0f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
-                epi_fetch<T>(a, ext[mt][nt], mc, n0 < a.N ? n0 : 0, bz);
+                epi_fetch<T>(a, ext[nt], mc, n0 < a.N ? n0 : 0, bz);
             }
-        }
-#pragma unroll
-        for (int mt = 0; mt < WM; ++mt) {
+        };
+        auto apply = [&](const uint4 (&ext)[4], int mt) {
             const int m = m_blk + wm0 + mt * 16 + (l & 15);
+            const int mc = m < a.M ? m : a.M - 1;
+            const float rs = a.rowscale ? a.rowscale[mc / a.rows_per_scale] : 1.0f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
-                if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], ext[mt][nt], acc[nt][mt], m, n0, rs[mt], bz);
+                if (m < a.M && n0 < a.N) epi_apply<T>(a, bias4[nt], ext[nt], acc[nt][mt], m, n0, rs, bz);
+            }
+        };
+        uint4 ea[4], eb[4];
+        fetch(ea, 0);
+#pragma unroll
+        for (int mt = 0; mt < WM; mt += 2) {
+            if (mt + 1 < WM) fetch(eb, mt + 1);
+            apply(ea, mt);
+            if (mt + 1 < WM) {
+                if (mt + 2 < WM) fetch(ea, mt + 2);
+                apply(eb, mt + 1);
             }
         }
     }
@@ -931,7 +940,7 @@ int launch_tr(const GemmArgs& a, hipStream_t st) {
 //     memory into registers (16 B per lane, k-contiguous rows -- no LDS, no barrier), X is read exactly once for
 //     all columns of the panel, and the strip after next is requested before the epilogue of the current one.
 // 2 workgroups = 16 independent waves per CU keep loads, MFMAs and stores of different strips in flight together.
-template <typename T, int NCH, bool WT, bool EXT>
+template <typename T, int NCH, bool WT, int EXT>        // EXT: 0 no row-dependent epilogue operand, 1 GELU' input (T), 2 f32 residual
 __global__ __launch_bounds__(512, (NCH == 2 && !EXT) ? 4 : 2) void gemm_stream_kernel(GemmArgs a, int bnp) {   // 2nd argument: waves per SIMD (2 workgroups per CU = 4)
     constexpr int SZ = TT<T>::SZ, E = TT<T>::E16;
     constexpr int RL = NCH * 64;                          // bytes of K per LDS row (NCH even: whole 128-byte swizzle groups)
@@ -1043,50 +1052,112 @@ __global__ __launch_bounds__(512, (NCH == 2 && !EXT) ? 4 : 2) void gemm_stream_k
             const int m = m_lane + mt * 16;
             rs[mt] = a.rowscale ? a.rowscale[(m < a.M ? m : a.M - 1) / a.rows_per_scale] : 1.0f;
         }
-#pragma unroll 1
-        for (int nb = 0; nb < nnb; ++nb) {
-            f32x4 acc[4][2];
-            zero_acc(acc);
+        if constexpr (EXT == 1 && NCH <= 4) {
+            // GELU' input of the fc2 input gradients: its loads for column block nb + 1 are issued BEFORE block nb is applied and
+            // stored (two register sets, two blocks per loop trip).  Fetched and consumed inside the same block, every (block,
+            // 16-row group) exposed one full memory latency -- 14 per strip at N = 448 -- and the waves of this variant sat in
+            // s_waitcnt for 3/4 of their cycles (SQ_WAIT_ANY 0.75).  vmcnt retires in issue order, so waiting for these loads
+            // never waits for the stores issued after them.  (NCH = 8 has no registers left for the second set.)
+            constexpr int EW = sizeof(T) == 2 ? 1 : 2;                       // uint2 words per 4 elements of T
+            struct ExtSet { uint2 v[2][4][EW]; };
+            auto fetch_ext = [&](ExtSet& e, int nb) {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                uint4 af[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = nb * 64 + i * 16 + (l & 15);
-                    af[i] = *reinterpret_cast<const uint4*>(smem + row * RL + ((c * 64 + ((l >> 4) << 4)) ^ swz(row)));
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    mma_chunk<T>(acc[i][0], af[i], xf[0][c]);
-                    mma_chunk<T>(acc[i][1], af[i], xf[1][c]);
-                }
-            }
-            if (nb == nnb - 1 && strip + stride < strips) issue_x(strip + stride);   // request the next strip, then write this one out
-            // EXT (a row-dependent operand: GELU' input or residual): the 4 quads of 16 rows are fetched together before they are
-            // applied; otherwise quad by quad, which keeps the kernel at 4 waves per SIMD
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int m = m_lane + mt * 16;
-                const int mc = m < a.M ? m : a.M - 1;
-                uint4 ext[4];
-                if constexpr (EXT) {
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int m = m_lane + mt * 16;
+                    const T* ap = reinterpret_cast<const T*>(a.aux) + (long)(m < a.M ? m : a.M - 1) * a.ldaux;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int n0 = n_blk + nb * 64 + i * 16 + ((l >> 4) << 2);
-                        epi_fetch<T>(a, ext[i], mc, n0 < a.N ? n0 : 0, 0);
+                        const uint2* src = reinterpret_cast<const uint2*>(ap + (n0 < a.N ? n0 : 0));
+#pragma unroll
+                        for (int q = 0; q < EW; ++q) e.v[mt][i][q] = src[q];
                     }
                 }
+            };
+            auto block = [&](int nb, const ExtSet& cur, ExtSet& nxt) {
+                f32x4 acc[4][2];
+                zero_acc(acc);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n0 = n_blk + nb * 64 + i * 16 + ((l >> 4) << 2);
-                    if (m < a.M && n0 < a.N) epi_apply<T>(a, *reinterpret_cast<const f32x4*>(sbias + (n0 - n_blk)), ext[i], acc[i][mt], m, n0, rs[mt], 0);
+                for (int c = 0; c < NCH; ++c) {
+                    uint4 af[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = nb * 64 + i * 16 + (l & 15);
+                        af[i] = *reinterpret_cast<const uint4*>(smem + row * RL + ((c * 64 + ((l >> 4) << 4)) ^ swz(row)));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        mma_chunk<T>(acc[i][0], af[i], xf[0][c]);
+                        mma_chunk<T>(acc[i][1], af[i], xf[1][c]);
+                    }
+                }
+                if (nb + 1 < nnb) fetch_ext(nxt, nb + 1);
+                if (nb == nnb - 1 && strip + stride < strips) issue_x(strip + stride);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int m = m_lane + mt * 16;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int n0 = n_blk + nb * 64 + i * 16 + ((l >> 4) << 2);
+                        const uint4 ex = EW == 1 ? make_uint4(cur.v[mt][i][0].x, cur.v[mt][i][0].y, 0u, 0u)
+                                                 : make_uint4(cur.v[mt][i][0].x, cur.v[mt][i][0].y, cur.v[mt][i][EW - 1].x, cur.v[mt][i][EW - 1].y);
+                        if (m < a.M && n0 < a.N) epi_apply<T>(a, *reinterpret_cast<const f32x4*>(sbias + (n0 - n_blk)), ex, acc[i][mt], m, n0, rs[mt], 0);
+                    }
+                }
+            };
+            ExtSet ea, eb;
+            fetch_ext(ea, 0);
+#pragma unroll 1
+            for (int nb = 0; nb < nnb; nb += 2) {
+                block(nb, ea, eb);
+                if (nb + 1 < nnb) block(nb + 1, eb, ea);
+            }
+        } else {
+#pragma unroll 1
+            for (int nb = 0; nb < nnb; ++nb) {
+                f32x4 acc[4][2];
+                zero_acc(acc);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    uint4 af[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = nb * 64 + i * 16 + (l & 15);
+                        af[i] = *reinterpret_cast<const uint4*>(smem + row * RL + ((c * 64 + ((l >> 4) << 4)) ^ swz(row)));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        mma_chunk<T>(acc[i][0], af[i], xf[0][c]);
+                        mma_chunk<T>(acc[i][1], af[i], xf[1][c]);
+                    }
+                }
+                if (nb == nnb - 1 && strip + stride < strips) issue_x(strip + stride);   // request the next strip, then write this one out
+                // a row-dependent operand (EXT): the 4 quads of 16 rows are fetched together before they are applied; otherwise quad
+                // by quad, which keeps the kernel at 4 waves per SIMD
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int m = m_lane + mt * 16;
+                    const int mc = m < a.M ? m : a.M - 1;
+                    uint4 ext[4];
+                    if constexpr (EXT != 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int n0 = n_blk + nb * 64 + i * 16 + ((l >> 4) << 2);
+                            epi_fetch<T>(a, ext[i], mc, n0 < a.N ? n0 : 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int n0 = n_blk + nb * 64 + i * 16 + ((l >> 4) << 2);
+                        if (m < a.M && n0 < a.N) epi_apply<T>(a, *reinterpret_cast<const f32x4*>(sbias + (n0 - n_blk)), ext[i], acc[i][mt], m, n0, rs[mt], 0);
+                    }
                 }
             }
         }
     }
 }
 
-template <typename T, int NCH, bool WT, bool EXT>
+template <typename T, int NCH, bool WT, int EXT>
 int launch_stream(const GemmArgs& a, hipStream_t st) {
     constexpr int RL = NCH * 64;
     const int maxb = ((64 * 1024) / RL) & ~63;                      // panel columns that fit 64 KB (2 workgroups per CU)
@@ -1098,16 +1169,17 @@ int launch_stream(const GemmArgs& a, hipStream_t st) {
     int gx = fw_cdiv(strips, 8);
     const int cap = 512 / ny > 0 ? 512 / ny : 1;                    // 256 CUs x 2 workgroups
     if (gx > cap) gx = cap;
-    FW_KNAME("gemm_stream_kernel<%s,%d,%s,%s>", tname<T>(), NCH, FW_B(WT), FW_B(EXT));
+    FW_KNAME("gemm_stream_kernel<%s,%d,%s,%d>", tname<T>(), NCH, FW_B(WT), EXT);
     hipLaunchKernelGGL((gemm_stream_kernel<T, NCH, WT, EXT>), dim3(gx, ny), dim3(512), lds, st, a, bnp);
     FW_LAUNCH_RET();
 }
 
 template <typename T, int NCH>
 int dispatch_stream_n(const GemmArgs& a, int wt, hipStream_t st) {
-    const bool ext = a.act == 2 || a.residual != nullptr;           // a row-dependent epilogue operand is prefetched (more registers)
-    if (wt) return ext ? launch_stream<T, NCH, true, true>(a, st) : launch_stream<T, NCH, true, false>(a, st);
-    return ext ? launch_stream<T, NCH, false, true>(a, st) : launch_stream<T, NCH, false, false>(a, st);
+    // a row-dependent epilogue operand is prefetched one column block ahead (more registers): 1 = GELU' input, 2 = f32 residual
+    const int ext = a.act == 2 ? 1 : (a.residual != nullptr ? 2 : 0);
+    if (wt) return ext == 1 ? launch_stream<T, NCH, true, 1>(a, st) : ext == 2 ? launch_stream<T, NCH, true, 2>(a, st) : launch_stream<T, NCH, true, 0>(a, st);
+    return ext == 1 ? launch_stream<T, NCH, false, 1>(a, st) : ext == 2 ? launch_stream<T, NCH, false, 2>(a, st) : launch_stream<T, NCH, false, 0>(a, st);
 }
 template <typename T>
 int dispatch_stream(const GemmArgs& a, int wt, hipStream_t st) {

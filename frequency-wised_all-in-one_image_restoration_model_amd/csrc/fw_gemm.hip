@@ -1297,10 +1297,15 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
             if (ring == 4) return launch_tr_ring<true, 32, 5>(a, st);
             return launch_tr<true>(a, st);
         }
-        static const long tr_min_tiles = getenv("FW_GEMM_TR_MIN_TILES") ? atol(getenv("FW_GEMM_TR_MIN_TILES")) : 384;
+        static const long tr_min_tiles = getenv("FW_GEMM_TR_MIN_TILES") ? atol(getenv("FW_GEMM_TR_MIN_TILES")) : 200;   // 200..383 tiles: 77 -> 47 us at 4096 x 896 x 3584; below 200 the old kernel's 128 x 64 tiles fill more CUs
         if (!x_trans && (use_tr & 2) && !xsum && (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk >= tr_min_tiles) {
             g_last_variant = 100001;
             if (ring == 5) return launch_tr_ring<false, 64, 2>(a, st);
+            // 3 stages = 96 KB = ONE workgroup per CU: fastest while the epilogue is a plain store.  An epilogue with an operand of its
+            // own (GELU' input) keeps the CU's only 4 waves off the MFMAs for as long as the K loop took; 2 stages = 64 KB lets a
+            // second workgroup's K loop run under it: 135 -> 105 us at 16384 x 1792 x 448, 101 -> 71 us at 4096 x 3584 x 896.
+            static const int np2 = getenv("FW_GEMM_TR_NP2") ? atoi(getenv("FW_GEMM_TR_NP2")) : 1;
+            if (ring == 1 && np2 && !plain_epilogue(a)) return launch_tr_ring<false, 64, 2>(a, st);
             if (ring == 2 || ring == 1) return launch_tr_ring<false, 64, 3>(a, st);
             if (ring == 3 || ring == 4) return launch_tr_ring<false, 64, 4>(a, st);
             return launch_tr<false>(a, st);

@@ -277,7 +277,7 @@ def attn_profile(engine, batch, reps=4):
             real_call('fw_attn_bwd', dty, D, nkt, lfs, qkv, qkv[:, Cp:], qkv[:, Cp + C:], qkv.stride(0), out, out.stride(0), dout,
                       dout.stride(0), lse, tables, coef, tab, dqkv, dqkv[:, Cp:], dqkv[:, Cp + C:],
                       d2[:, Cp:] if d2 is not None else None, d2[:, Cp + C:] if d2 is not None else None, dqkv.stride(0), dtab, dcoef,
-                      B, H, W, heads, L, mode, shift, float(D) ** -0.5)
+                      B, H, W, heads, L, mode, shift, float(D) ** -0.5, Cp - C)
 
         sets = [operands() for _ in range(reps)]
         run = fwd if name == 'fw_attn_fwd' else bwd

@@ -54,6 +54,7 @@ struct AttnArgs {
     float* dbias;                                     // [ntab][225][heads], same layout as the bias tables
     float* dcoef;                                     // [B][heads][3]
     int chunks;                                       // windows are split into `chunks` per (band, head)
+    int dq_pad;                                       // zero columns written behind the LAST head's dq columns (0, or up to the next multiple of 8)
 };
 
 // ---- LFS panel offsets (in elements of T), see build_lfs_tables() on the host side -------------
@@ -149,12 +150,14 @@ template <typename T, int D> struct TileLoad {
     }
 };
 // Copy rows r0..r0+15 of a [64][D] LDS tile -> the matching window rows of one head; ONE wave (its own strip).
+// extra: granules of the tile's zero padding (columns D .. D + extra * CB / SZ - 1: products of zero-padded operand columns) copied too
 template <typename T, int D>
-FW_DEV void store_rows16(const char* tile, char* base, long ld, int n, int wy, int wx, int H, int W, int shift, int col, int r0) {
+FW_DEV void store_rows16(const char* tile, char* base, long ld, int n, int wy, int wx, int H, int W, int shift, int col, int r0, int extra = 0) {
     using G = Geo<T, D>;
     const int l = lane_id();
-    for (int idx = l; idx < 16 * G::CH; idx += 64) {
-        const int t = r0 + idx / G::CH, s = idx % G::CH;
+    const int ng = G::CH + extra;
+    for (int idx = l; idx < 16 * ng; idx += 64) {
+        const int t = r0 + idx / ng, s = idx % ng;
         char* dst = base + (token_row(n, wy, wx, t, H, W, shift) * ld + col) * G::SZ;
         if (G::CB == 16) *reinterpret_cast<uint4*>(dst + s * 16) = *reinterpret_cast<const uint4*>(tile + t * G::LDR + s * 16);
         else *reinterpret_cast<uint2*>(dst + s * 8) = *reinterpret_cast<const uint2*>(tile + t * G::LDR + s * 8);
@@ -435,6 +438,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_kernel(AttnArgs a) {
     const int nWx = a.W / 8, nWy = a.H / 8, nW = nWx * nWy;
     // grid: x = chunk, y = head, z = query band
     const int h = blockIdx.y, lq = blockIdx.z;
+    const int dqx = (h == a.heads - 1) ? a.dq_pad * G::SZ / G::CB : 0;       // granules of zero padding behind the last head's dq
     const int i = w * 16 + (l & 15);                         // the query of this lane's score columns
     f32x4 dbacc[NKT][4];                                     // bias-gradient accumulators of (i, j = 16 jt + 4 (l>>4) + r), all windows
 #pragma unroll
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int m = 0; m < G::DT; ++m) store_acc_T<T>(sY, G::LDR, m * 16, w * 16, dq[m] * a.scale);         // dQ [i][d], own rows i
         wave_fence();
-        store_rows16<T, D>(sY, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+        store_rows16<T, D>(sY, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16, dqx);
         // the next window's Q / dO loads touch neither sY nor anything a wave still reads
     }
     flush_coef();
@@ -1010,6 +1014,7 @@ __global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
     const int l = lane_id(), w = wave_id();
     const int nWx = a.W / 8, nWy = a.H / 8, nW = nWx * nWy;
     const int h = blockIdx.y, lq = blockIdx.z;
+    const int dqx = (h == a.heads - 1) ? a.dq_pad * G::SZ / G::CB : 0;       // granules of zero padding behind the last head's dq
     const int i = w * 16 + (l & 15);
     const int per = (a.nwin + gridDim.x - 1) / gridDim.x;
     const int win_begin = blockIdx.x * per, win_end = min(a.nwin, win_begin + per);
@@ -1178,7 +1183,7 @@ __global__ __launch_bounds__(NTH, 1) void attn2_bwd_kernel(AttnArgs a) {
         }
         wave_fence();
         store_rows16<T, D>(sY, a.dk, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
-        store_rows16<T, D>(sV, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+        store_rows16<T, D>(sV, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16, dqx);
     }
     flush_coef();
     lds_barrier();
@@ -1338,6 +1343,7 @@ __global__ __launch_bounds__(NTH, 1) void attn2x_bwd_kernel(AttnArgs a) {
     const int l = lane_id(), w = wave_id();
     const int nWx = a.W / 8, nWy = a.H / 8, nW = nWx * nWy;
     const int h = blockIdx.y, lq = blockIdx.z;
+    const int dqx = (h == a.heads - 1) ? a.dq_pad * G::SZ / G::CB : 0;       // granules of zero padding behind the last head's dq
     const int i = w * 16 + (l & 15);
     const int per = (a.nwin + gridDim.x - 1) / gridDim.x;
     const int win_begin = blockIdx.x * per, win_end = min(a.nwin, win_begin + per);
@@ -1484,7 +1490,7 @@ __global__ __launch_bounds__(NTH, 1) void attn2x_bwd_kernel(AttnArgs a) {
             char* dkp = kt_slot(lq, lk[kt]) == 1 ? a.dk2 : a.dk;
             store_rows16<T, D>(sY + kt * G::TILE_D, dkp, a.ldd, lk[kt] * a.B + b, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
         }
-        store_rows16<T, D>(sV, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16);
+        store_rows16<T, D>(sV, a.dq, a.ldd, nq, wy, wx, a.H, a.W, a.shift, h * D, w * 16, dqx);
     }
     float* fold = reinterpret_cast<float*>(smem + S::OFF_T);          // tiles are dead: fold the (i, j) pairs into the 225 relative positions
 #pragma unroll
@@ -1614,7 +1620,7 @@ extern "C" int fw_attn_bwd(int dtype, int D, int nkt, int lfs, const void* q, co
                            const void* out, long ldo, const void* dout, long lddo, const float* lse, const float* bias,
                            const float* coef, const void* lfs_tab, void* dq, void* dk, void* dv, void* dk2, void* dv2,
                            long ldd, float* dbias, float* dcoef, int B, int H, int W, int heads, int L, int mode,
-                           int shift, float scale, void* stream) {
+                           int shift, float scale, int dq_pad, void* stream) {
     FW_CHECK_ARG(q && k && v && dout && lse && bias && dq && dk && dv && dbias);
     FW_CHECK_ARG(H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8 && B > 0 && heads > 0 && L >= 1 && L <= 3);
     FW_CHECK_ARG(shift >= 0 && shift < 8 && (shift == 0 || (H > 8 && W > 8)));
@@ -1631,6 +1637,9 @@ extern "C" int fw_attn_bwd(int dtype, int D, int nkt, int lfs, const void* q, co
     a.nwin = B * (H / 8) * (W / 8);
     a.dout = (const char*)dout; a.lddo = lddo; a.dq = (char*)dq; a.dk = (char*)dk; a.dv = (char*)dv;
     a.dk2 = (char*)dk2; a.dv2 = (char*)dv2; a.ldd = ldd; a.dbias = dbias; a.dcoef = dcoef;
+    FW_CHECK_ARG(dq_pad == 0 || (dq_pad > 0 && dq_pad < 8 && (heads * D + dq_pad) % 8 == 0));
+    FW_CHECK_ARG(dq_pad == 0 || ((dq_pad * sz) % (((D * sz) % 16 == 0) ? 16 : 8) == 0 && (D + dq_pad) * sz <= ((D * sz + 63) / 64) * 64));
+    a.dq_pad = dq_pad;
     static const int bwd_wgs = getenv("FW_ATTN_BWD_WGS") ? atoi(getenv("FW_ATTN_BWD_WGS")) : 1024;
     int chunks = bwd_wgs / (heads * L);          // 4-wave workgroups, 2 per CU: about two rounds of the chip
     if (chunks < 1) chunks = 1;

@@ -98,6 +98,56 @@ def shadow(param, kind='plain'):
     return out
 
 
+def _shadow_part(param, key, out, recipe):
+    """Keep `out` (a view into a buffer shared with other parameters) as the cached copy `key` of `param`: filled now, re-derived by
+    refresh_shadows / on a stale stamp like every other entry."""
+    p = param.detach()
+    slot = _shadow.get(id(param))
+    ent = slot[1] if slot is not None and slot[0]() is param else None
+    stamp = (param._version, config.shadow_epoch, p.data_ptr())
+    if ent is not None and key in ent and ent[key][0] == stamp and ent[key][1].data_ptr() == out.data_ptr():
+        return
+    src, dims, strides = recipe
+    assert src.data_ptr() == p.data_ptr() and src.is_contiguous()
+    ops.permute3(src, out, dims, strides)
+    if ent is None:
+        ent = {}
+        pid = id(param)
+        _shadow[pid] = (weakref.ref(param, lambda _r, pid=pid: _shadow.pop(pid, None)), ent)
+    ent[key] = (stamp, out, recipe)
+
+
+_qkv_cat = {}                 # id(wq) -> (weakref(wq), {dtype: (W [Cp + 2C][ld], bias f32 [Cp + 2C])})
+
+
+def shadow_qkv(wq, bq, wkv, bkv):
+    """to_q / to_kv whose width C is not a multiple of 8 (the C = 28 stage): ONE operand [Cp + 2C][K] = [Wq ; 0 ; Wkv] and one bias
+    [bq ; 0 ; bkv], so that the projection writes whole rows of the q | pad | k | v buffer in one GEMM (two GEMMs wrote 56- and
+    112-byte pieces of every 176-byte row: 65 + 72 us against 45 us for the same bytes at 786 432 tokens) and its input gradient
+    reads the whole gradient buffer in one.  The pad rows are zeroed once; the two halves are ordinary shadow entries of their
+    parameters (functional.refresh_shadows re-derives them after every optimizer step)."""
+    dtype = config.compute_dtype
+    C, K = wq.shape
+    Cp = (C + 7) // 8 * 8
+    slot = _qkv_cat.get(id(wq))
+    bufs = slot[1] if slot is not None and slot[0]() is wq else None
+    if bufs is None:
+        bufs = {}
+        pid = id(wq)
+        _qkv_cat[pid] = (weakref.ref(wq, lambda _r, pid=pid: _qkv_cat.pop(pid, None)), bufs)
+    if dtype not in bufs:
+        ld = (K + 7) // 8 * 8
+        bufs[dtype] = (torch.zeros((Cp + 2 * C, ld), dtype=dtype, device=wq.device)[:, :K],
+                       torch.zeros((Cp + 2 * C,), dtype=torch.float32, device=wq.device))
+    W, b = bufs[dtype]
+    ld = W.stride(0)
+    _shadow_part(wq, ('qcat', dtype), W[:C], (wq.detach().reshape(C, K), (1, C, K), (0, ld, 1)))
+    _shadow_part(wkv, ('kvcat', dtype), W[Cp:], (wkv.detach().reshape(2 * C, K), (1, 2 * C, K), (0, ld, 1)))
+    _shadow_part(bq, ('qcat', torch.float32), b[:C], (bq.detach().reshape(1, C), (1, 1, C), (0, 0, 1)))
+    _shadow_part(bkv, ('kvcat', torch.float32), b[Cp:], (bkv.detach().reshape(1, 2 * C), (1, 1, 2 * C), (0, 0, 1)))
+    return W, b
+
+
 _refresh_tables = {}          # which -> (signature, device table, device prefix, num, total blocks)
 
 
@@ -340,8 +390,13 @@ class QKVFn(torch.autograd.Function):
             w3 = fused['sw'] if x.dtype == torch.bfloat16 and 'sw' in fused else (fused['w'] if x.dtype == torch.float32 else None)
         else:
             w3 = None
+        ctx.cat = None
         if w3 is not None:
             ops.gemm(x, w3, M, 3 * C, K, out=buf[:, :3 * C], bias=fused['b'])
+        elif Cp != C and bq is not None and bkv is not None:
+            wc, bc = shadow_qkv(wq, bq, wkv, bkv)             # [Wq ; 0 ; Wkv]: whole rows of the buffer (the pad columns become 0)
+            ops.gemm(x, wc, M, Cp + 2 * C, K, out=buf, bias=bc)
+            ctx.cat = wc
         else:
             ops.gemm(x, shadow(wq), M, C, K, out=buf[:, :C], bias=bq)
             ops.gemm(x, shadow(wkv), M, 2 * C, K, out=buf[:, Cp:], bias=bkv)
@@ -366,6 +421,10 @@ class QKVFn(torch.autograd.Function):
         dq, dkv = dbuf[:, :C], dbuf[:, Cp:]
         dwq, dbq = _wgrad(dq, x, C, K, M, wq, ctx.bq)
         dwkv, dbkv = _wgrad(dkv, x, 2 * C, K, M, wkv, ctx.bkv)
+        if ctx.cat is not None and getattr(dbuf, '_fw_zero_pad', False):
+            # the attention backward wrote zeros into the pad columns (fw_attn_bwd dq_pad): the whole buffer is one operand
+            ops.gemm(dbuf, ctx.cat, M, K, Cp + 2 * C, w_trans=True, out=dx)
+            return dx, dwq, dbq, dwkv, dbkv, None
         tmp = torch.empty((M, K), dtype=torch.float32, device=x.device)
         ops.gemm(dq, shadow(wq), M, K, C, w_trans=True, out=tmp)
         ops.gemm(dkv, shadow(wkv), M, K, 2 * C, w_trans=True, out=dx, residual=tmp)
@@ -424,9 +483,10 @@ class WindowAttnFn(torch.autograd.Function):
         call('fw_attn_bwd', dt(qkv.dtype), D, nkt, lfs, qkv, qkv[:, Cp:], qkv[:, Cp + C:], qkv.stride(0), out, out.stride(0),
              dout, dout.stride(0), lse, tables, coef, tab, dqkv, dqkv[:, Cp:], dqkv[:, Cp + C:],
              d2[:, Cp:] if d2 is not None else None, d2[:, Cp + C:] if d2 is not None else None, dqkv.stride(0), dtab, dcoef,
-             B, H, W, heads, L, mode, shift, float(D) ** -0.5)
+             B, H, W, heads, L, mode, shift, float(D) ** -0.5, Cp - C)      # the pad between dq and dk gets zeros: dqkv is ONE GEMM operand
         if nkt == 2:
             call('fw_add_rows', dt(qkv.dtype), d2[:, Cp:], d2.stride(0), dqkv[:, Cp:], dqkv.stride(0), rows, 2 * C)
+        dqkv._fw_zero_pad = True                               # q | 0 | k | v: defined everywhere
         return dqkv, rtab, rcoef, None, None, None
 
 

@@ -229,7 +229,7 @@ def attn_bwd(qkv, out, dout, lse, C, B, H, W, heads, L, mode, shift, bias, dbias
     call('fw_attn_bwd', dt(qkv.dtype), D, nkt, lfs, qkv, qkv[:, C:], qkv[:, 2 * C:], _ld(qkv), out, _ld(out), dout, _ld(dout),
          lse, bias, coef, tab, dqkv, dqkv[:, C:], dqkv[:, 2 * C:], d2[:, C:] if d2 is not None else None,
          d2[:, 2 * C:] if d2 is not None else None, _ld(dqkv),
-         dbias_dense, dcoef, B, H, W, heads, L, mode, shift, float(D) ** -0.5)
+         dbias_dense, dcoef, B, H, W, heads, L, mode, shift, float(D) ** -0.5, 0)
     if nkt == 2:
         call('fw_add_rows', dt(qkv.dtype), d2[:, C:], _ld(d2), dqkv[:, C:], _ld(dqkv), rows, 2 * C)
     return dqkv

@@ -80,11 +80,13 @@ int fw_attn_fwd(int dtype, int D, int nkt, int lfs, const void* q, const void* k
                 float* lse, const float* bias, const float* coef, const void* lfs_tab, int B, int H, int W, int heads, int L,
                 int mode, int shift, float scale, void* stream);
 /* dbias: f32 [L*L][225][heads] (layout of `bias`); dcoef: f32 [B][heads][3]; both accumulated.  dk2/dv2: second slot of
- * key gradients when nkt == 2 (each key band is attended by two query bands). */
+ * key gradients when nkt == 2 (each key band is attended by two query bands).  dq_pad: columns behind the last head's dq columns
+ * that are written too, with zeros (0, or roundup(heads*D, 8) - heads*D when dq | pad | dk | dv share one buffer: the pad then
+ * holds defined values and the buffer can be one GEMM operand). */
 int fw_attn_bwd(int dtype, int D, int nkt, int lfs, const void* q, const void* k, const void* v, long ld, const void* out,
                 long ldo, const void* dout, long lddo, const float* lse, const float* bias, const float* coef,
                 const void* lfs_tab, void* dq, void* dk, void* dv, void* dk2, void* dv2, long ldd, float* dbias,
-                float* dcoef, int B, int H, int W, int heads, int L, int mode, int shift, float scale, void* stream);
+                float* dcoef, int B, int H, int W, int heads, int L, int mode, int shift, float scale, int dq_pad, void* stream);
 
 /* ---- LeFF depthwise 3x3 (net/utils/leff.py:104-111).  Both pre-activations (h) and GELU outputs (g) are kept:
  * fwd: h2 = dwconv(g1) + bias, g2 = GELU(h2);  bwd: dh1 = GELU'(h1) * convT(dh2), dw/dbias accumulated.

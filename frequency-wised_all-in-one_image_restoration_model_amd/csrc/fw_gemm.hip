@@ -922,6 +922,130 @@ int launch_ring(const GemmArgs& a, hipStream_t st) {
     return plain_epilogue(a) ? launch_ring_p<T, BN, NS, true>(a, st) : launch_ring_p<T, BN, NS, false>(a, st);
 }
 
+// ---- the NT product on 64-BYTE K steps: four 16 KB stages in the same 64 KB (BN = 128), three loads in flight ----------------
+// gemm_ring_kernel above holds 2 x 32 KB stages: one stage in flight per workgroup, 62 % of its wave cycles parked in s_waitcnt
+// (SQ_WAIT_ANY).  The weight-gradient kernel -- four 16 KB stages of 32-deep steps in the same LDS, two workgroups per CU -- waits
+// 33 %.  This is that shape for k-contiguous operands: LDS rows of 64 bytes, 16-byte slot p of row r stored at slot
+// p ^ ((r >> 2) & 3) (16 consecutive rows x one slot = 64 distinct banks for the fragment's ds_read_b128), filled by LDS-DMA with
+// the swizzle applied to the per-lane SOURCE address (one wave instruction = 16 rows x 64 B = 1 KB, lane-linear in LDS).
+// Also takes K that is a multiple of 64 bytes but not of 128 (K = 224, 672 in bf16).
+constexpr int ROW64 = 64;
+FW_DEV int swz64(int r) { return (r >> 2) & 3; }
+template <typename T, int ROWS> struct GldsKc64 {
+    static constexpr int NI = ROWS / 64;                     // wave instructions per thread and stage (4 waves x 16 rows each)
+    const char* src[NI];
+    int loff[NI];
+    FW_MEM void init(const char* base, long ld, int row0, int rows_total, int kbyte0) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int R0 = (wave * NI + it) * 16;
+            const int r = R0 + (lane >> 2), p = lane & 3;
+            int gr = row0 + r;
+            if (gr >= rows_total) gr = rows_total - 1;     // rows past the end only feed masked outputs
+            src[it] = base + (long)gr * ld * TT<T>::SZ + kbyte0 + ((p ^ swz64(r)) << 4);
+            loff[it] = R0 * ROW64;
+        }
+    }
+    FW_MEM void issue(int step, char* tile) const {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) glds16_asm(src[it] + (long)step * ROW64, tile + loff[it]);
+    }
+};
+FW_DEV uint4 frag_sw64(const char* tile, int row0) {
+    const int l = lane_id();
+    const int row = row0 + (l & 15);
+    return *reinterpret_cast<const uint4*>(tile + row * ROW64 + (((l >> 4) ^ swz64(row)) << 4));
+}
+
+template <typename T, int BN, int NS, bool PLAIN>
+__global__ __launch_bounds__(256) void gemm_ring64_kernel(GemmArgs a) {
+    constexpr int KT = ROW64 / TT<T>::SZ;
+    constexpr int WM = (BN == 128) ? 4 : 2;
+    constexpr int XBYTES = BM * ROW64, WBYTES = BN * ROW64, STAGE = XBYTES + WBYTES;
+    constexpr int LPS = BM / 64 + BN / 64;
+    static_assert(NS >= 3 && NS <= 5, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto xs = [&](int i) -> char* { return smem + i * STAGE; };
+    auto ws = [&](int i) -> char* { return smem + i * STAGE + XBYTES; };
+    const int wave = threadIdx.x >> 6;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        if (gridDim.z > 1) {
+            const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const unsigned w = xcd_contiguous(lin, total);
+            bx = (int)(w % gridDim.x);
+            by = (int)((w / gridDim.x) % gridDim.y);
+            bz = (int)(w / (gridDim.x * gridDim.y));
+        } else if (gridDim.z == 1 && gridDim.y > 1) {
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+            const unsigned w = xcd_contiguous(lin, total);
+            const unsigned per_band = 8 * gridDim.y;
+            const unsigned band = w / per_band, first = band * 8;
+            const unsigned gsz = min(gridDim.x - first, 8u);
+            bx = (int)(first + (w % per_band) % gsz);
+            by = (int)((w % per_band) / gsz);
+        }
+    }
+    const int m_blk = bx * BM, n_blk = by * BN;
+    const int wm0 = (BN == 128) ? (wave & 1) * 64 : wave * 32;
+    const int wn0 = (BN == 128) ? (wave >> 1) * 64 : 0;
+    const int k_begin = bz * a.kper;
+    const int k_end = min(a.K, k_begin + a.kper);
+    const int nsteps = (k_end - k_begin) / KT;           // whole steps (host: K and kper are multiples of KT)
+
+    f32x4 acc[4][WM];
+    zero_acc(acc);
+    GldsKc64<T, BM> gx;
+    GldsKc64<T, BN> gw;
+    gx.init(a.X, a.ldx, m_blk, a.M, k_begin * TT<T>::SZ);
+    gw.init(a.W, a.ldw, n_blk, a.N, k_begin * TT<T>::SZ);
+    auto issue = [&](int step, int buf) {
+        gx.issue(step, xs(buf));
+        gw.issue(step, ws(buf));
+    };
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nsteps) issue(p, p);
+    int buf = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const int younger = min(NS - 2, nsteps - 1 - s);
+        if (younger >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
+        else if (younger == NS - 3) wait_vmcnt<(NS - 3) * LPS>();
+        else if (NS >= 5 && younger == NS - 4) wait_vmcnt<(NS >= 5 ? NS - 4 : 0) * LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NS - 1 < nsteps) issue(s + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+        uint4 af[4], bfr[WM];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[m] = frag_sw64(ws(buf), wn0 + 16 * m);
+#pragma unroll
+        for (int n = 0; n < WM; ++n) bfr[n] = frag_sw64(xs(buf), wm0 + 16 * n);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < WM; ++n) mma_chunk<T>(acc[m][n], af[m], bfr[n]);
+        buf = buf + 1 == NS ? 0 : buf + 1;
+    }
+    tile_epilogue<T, WM, PLAIN>(a, acc, m_blk, n_blk, wm0, wn0, bz);
+}
+
+template <typename T, int BN, int NS, bool PLAIN>
+int launch_ring64_p(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)NS * (BM + BN) * ROW64;
+    FW_SET_LDS_ONCE((gemm_ring64_kernel<T, BN, NS, PLAIN>), lds);
+    dim3 grid(fw_cdiv(a.M, BM), fw_cdiv(a.N, BN), a.splitk);
+    FW_KNAME("gemm_ring64_kernel<%s,%d,%d,%s>", tname<T>(), BN, NS, FW_B(PLAIN));
+    hipLaunchKernelGGL((gemm_ring64_kernel<T, BN, NS, PLAIN>), grid, dim3(256), lds, st, a);
+    FW_LAUNCH_RET();
+}
+template <typename T, int BN, int NS>
+int launch_ring64(const GemmArgs& a, hipStream_t st) {
+    return plain_epilogue(a) ? launch_ring64_p<T, BN, NS, true>(a, st) : launch_ring64_p<T, BN, NS, false>(a, st);
+}
+
 template <bool XT>
 int launch_tr(const GemmArgs& a, hipStream_t st) {
     const size_t lds = 4 * 64 * 256;
@@ -1206,12 +1330,22 @@ int dispatch_trans(const GemmArgs& a, int xt, int wt, hipStream_t st) {
     const bool whole = a.K % kt == 0;
     const bool gx = !xt && whole && a.x_op == 0, gw = !wt && whole && a.w_op == 0;
     if (!xt && !wt) {
+        // 64-byte K steps: for K that is not a whole number of 128-byte steps (K = 224, 672 in bf16: the round-1 tile kernel took
+        // those with register staging: 28.5 -> 19.5 us at 16384 x 672 x 224).  On whole-step shapes it measured 5-10 % SLOWER than the
+        // two-stage 128-byte ring at BN = 128 (FW_GEMM_RING64=2 forces it everywhere, 0 disables it).
+        static const int ring64 = getenv("FW_GEMM_RING64") ? atoi(getenv("FW_GEMM_RING64")) : 1;
+        const int kt64 = 64 / TT<T>::SZ;
+        if (ring64 && a.x_op == 0 && a.w_op == 0 && a.K % kt64 == 0 && a.kper % kt64 == 0 && (ring64 == 2 || (!whole && BN == 128)))
+            return launch_ring64<T, BN, 4>(a, st);
         static const int ring = getenv("FW_GEMM_RING") ? atoi(getenv("FW_GEMM_RING")) : 1;        // 0: gemm_kernel (one stage in flight)
         if (gx && gw && ring && a.kper % kt == 0) {
             // LDS per workgroup decides the residency: 2 stages of 128 x 128 = 64 KB -> 2 workgroups per CU (ring 1, default);
             // deeper rings of one resident workgroup measured SLOWER (tools/probe/glds_probe.hip: 28 -> 42 us)
             if (ring == 2) return BN == 128 ? launch_ring<T, BN, 3>(a, st) : launch_ring<T, BN, 3>(a, st);
             if (ring == 3) return BN == 128 ? launch_ring<T, BN, 4>(a, st) : launch_ring<T, BN, 4>(a, st);
+            // BN = 64: 3 x 24 KB = 72 KB still leaves two workgroups per CU -- pays on long K loops (3072 x 448 x 3584: 48.6 -> 34.2 us,
+            // 1024 x 896 x 7168: 88.7 -> 62.1), costs 10-20 % on 7-step ones
+            if ((ring == 1 || ring == 4) && BN == 64 && a.kper >= 28 * kt) return launch_ring<T, BN, 3>(a, st);
             return launch_ring<T, BN, 2>(a, st);
         }
         if (gx && gw) return launch<T, BN, false, false, true, true>(a, st);

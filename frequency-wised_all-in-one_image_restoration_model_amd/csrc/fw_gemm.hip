@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void gemm_tr_kernel(GemmArgs a) {
     const int wm0 = (wave & 1) * 64, wn0 = (wave >> 1) * 64;
     const int k_begin = bz * a.kper;
     const int k_end = min(a.K, k_begin + a.kper);
-    const int nsteps = (k_end - k_begin) / KT;           // whole steps only (host guarantees K % 64 == 0)
+    const int nsteps = (k_end - k_begin) / KT;           // whole steps only (host guarantees K % KT == 0)
 
     f32x4 acc[4][WM], xsacc[WM];
     zero_acc(acc);
@@ -715,14 +715,43 @@ template <typename T, int ROWS> struct GldsKc {
     }
 };
 
+constexpr int ROW64 = 64;
+FW_DEV int swz64(int r) { return (r >> 2) & 3; }
+template <typename T, int ROWS> struct GldsKc64 {
+    static constexpr int NI = ROWS / 64;                     // wave instructions per thread and stage (4 waves x 16 rows each)
+    const char* src[NI];
+    int loff[NI];
+    FW_MEM void init(const char* base, long ld, int row0, int rows_total, int kbyte0) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int R0 = (wave * NI + it) * 16;
+            const int r = R0 + (lane >> 2), p = lane & 3;
+            int gr = row0 + r;
+            if (gr >= rows_total) gr = rows_total - 1;     // rows past the end only feed masked outputs
+            src[it] = base + (long)gr * ld * TT<T>::SZ + kbyte0 + ((p ^ swz64(r)) << 4);
+            loff[it] = R0 * ROW64;
+        }
+    }
+    FW_MEM void issue(int step, char* tile) const {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) glds16_asm(src[it] + (long)step * ROW64, tile + loff[it]);
+    }
+};
+FW_DEV uint4 frag_sw64(const char* tile, int row0) {
+    const int l = lane_id();
+    const int row = row0 + (l & 15);
+    return *reinterpret_cast<const uint4*>(tile + row * ROW64 + (((l >> 4) ^ swz64(row)) << 4));
+}
+
 template <bool XT, int KT, int NS, bool PLAIN>
 __global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
     using T = bf16raw;
-    static_assert(XT || KT == 64, "the k-contiguous X image is built for 64-deep steps");
     static_assert(NS >= 2 && NS <= 5, "ring depth");
     constexpr int WM = 4;
-    constexpr int XB = XT ? KT * 256 : 128 * LDS_ROW, WB = KT * 256, STAGE = XB + WB;
-    constexpr int LPS = (XT ? KT / 16 : 4) + KT / 16;          // global_load_lds instructions per thread and stage
+    constexpr bool X64 = !XT && KT == 32;                      // k-contiguous X in 64-byte rows (GldsKc64): 32-deep steps, e.g. K = 224
+    constexpr int XB = XT ? KT * 256 : 128 * (X64 ? ROW64 : LDS_ROW), WB = KT * 256, STAGE = XB + WB;
+    constexpr int LPS = (XT ? KT / 16 : (X64 ? 2 : 4)) + KT / 16;          // global_load_lds instructions per thread and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     auto xs = [&](int i) -> char* { return smem + i * STAGE; };
     auto ws = [&](int i) -> char* { return smem + i * STAGE + XB; };
@@ -750,7 +779,7 @@ __global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
     const int wm0 = (wave & 1) * 64, wn0 = (wave >> 1) * 64;
     const int k_begin = bz * a.kper;
     const int k_end = min(a.K, k_begin + a.kper);
-    const int nsteps = (k_end - k_begin) / KT;           // whole steps only (host guarantees K % 64 == 0)
+    const int nsteps = (k_end - k_begin) / KT;           // whole steps only (host guarantees K % KT == 0)
 
     f32x4 acc[4][WM], xsacc[WM];
     zero_acc(acc);
@@ -763,10 +792,13 @@ __global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
     gw.init(a.W, a.ldw, n_blk, a.N, k_begin);
     GldsKm<XT ? KT : 16> gxm;
     GldsKc<T, BM> gxc;
+    GldsKc64<T, BM> gxc64;
     if constexpr (XT) gxm.init(a.X, a.ldx, m_blk, a.M, k_begin);
+    else if constexpr (X64) gxc64.init(a.X, a.ldx, m_blk, a.M, k_begin * 2);
     else gxc.init(a.X, a.ldx, m_blk, a.M, k_begin * 2);
     auto issue = [&](int step, int buf) {
         if constexpr (XT) gxm.issue(step, xs(buf));
+        else if constexpr (X64) gxc64.issue(step, xs(buf));
         else gxc.issue(step, xs(buf));
         gw.issue(step, ws(buf));
     };
@@ -790,7 +822,7 @@ __global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) af[m] = frag_tr256(ws(buf), wn0 + 16 * m, c);
 #pragma unroll
-            for (int n = 0; n < WM; ++n) bfr[n] = XT ? frag_tr256(xs(buf), wm0 + 16 * n, c) : frag_sw(xs(buf), wm0 + 16 * n, c);
+            for (int n = 0; n < WM; ++n) bfr[n] = XT ? frag_tr256(xs(buf), wm0 + 16 * n, c) : (X64 ? frag_sw64(xs(buf), wm0 + 16 * n) : frag_sw(xs(buf), wm0 + 16 * n, c));
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -818,7 +850,7 @@ __global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
 
 template <bool XT, int KT, int NS, bool PLAIN>
 int launch_tr_ring_p(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)NS * ((XT ? KT * 256 : 128 * LDS_ROW) + KT * 256);
+    const size_t lds = (size_t)NS * ((XT ? KT * 256 : 128 * ((KT == 32) ? ROW64 : LDS_ROW)) + KT * 256);
     FW_SET_LDS_ONCE((gemm_tr_ring_kernel<XT, KT, NS, PLAIN>), lds);
     FW_KNAME("gemm_tr_ring_kernel<%s,%d,%d,%s>", FW_B(XT), KT, NS, FW_B(PLAIN));
     hipLaunchKernelGGL((gemm_tr_ring_kernel<XT, KT, NS, PLAIN>), dim3(fw_cdiv(a.M, 128), fw_cdiv(a.N, 128), a.splitk), dim3(256), lds, st, a);
@@ -929,35 +961,6 @@ int launch_ring(const GemmArgs& a, hipStream_t st) {
 // p ^ ((r >> 2) & 3) (16 consecutive rows x one slot = 64 distinct banks for the fragment's ds_read_b128), filled by LDS-DMA with
 // the swizzle applied to the per-lane SOURCE address (one wave instruction = 16 rows x 64 B = 1 KB, lane-linear in LDS).
 // Also takes K that is a multiple of 64 bytes but not of 128 (K = 224, 672 in bf16).
-constexpr int ROW64 = 64;
-FW_DEV int swz64(int r) { return (r >> 2) & 3; }
-template <typename T, int ROWS> struct GldsKc64 {
-    static constexpr int NI = ROWS / 64;                     // wave instructions per thread and stage (4 waves x 16 rows each)
-    const char* src[NI];
-    int loff[NI];
-    FW_MEM void init(const char* base, long ld, int row0, int rows_total, int kbyte0) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-        for (int it = 0; it < NI; ++it) {
-            const int R0 = (wave * NI + it) * 16;
-            const int r = R0 + (lane >> 2), p = lane & 3;
-            int gr = row0 + r;
-            if (gr >= rows_total) gr = rows_total - 1;     // rows past the end only feed masked outputs
-            src[it] = base + (long)gr * ld * TT<T>::SZ + kbyte0 + ((p ^ swz64(r)) << 4);
-            loff[it] = R0 * ROW64;
-        }
-    }
-    FW_MEM void issue(int step, char* tile) const {
-#pragma unroll
-        for (int it = 0; it < NI; ++it) glds16_asm(src[it] + (long)step * ROW64, tile + loff[it]);
-    }
-};
-FW_DEV uint4 frag_sw64(const char* tile, int row0) {
-    const int l = lane_id();
-    const int row = row0 + (l & 15);
-    return *reinterpret_cast<const uint4*>(tile + row * ROW64 + (((l >> 4) ^ swz64(row)) << 4));
-}
-
 template <typename T, int BN, int NS, bool PLAIN>
 __global__ __launch_bounds__(256) void gemm_ring64_kernel(GemmArgs a) {
     constexpr int KT = ROW64 / TT<T>::SZ;
@@ -1443,6 +1446,15 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
             if (ring == 2 || ring == 1) return launch_tr_ring<false, 64, 3>(a, st);
             if (ring == 3 || ring == 4) return launch_tr_ring<false, 64, 4>(a, st);
             return launch_tr<false>(a, st);
+        }
+    }
+    // the same input-gradient product with K a multiple of 32 only (K = 224, 336 is not): 32-deep steps, X in 64-byte rows
+    if (dtype == FW_DT_BF16 && w_trans && !x_trans && x_op == 0 && w_op == 0 && N > 64 && K % 64 != 0 && K % 32 == 0 && ldw % 8 == 0 && !xsum
+        && splitk == 1 && (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) >= 200) {
+        static const int r32 = getenv("FW_GEMM_TR_K32") ? atoi(getenv("FW_GEMM_TR_K32")) : 1;
+        if (r32 && plain_epilogue(a)) {          // with the GELU' epilogue the round-1 tile kernel stays ahead (45.9 vs 49.9 us at 16384 x 896 x 224)
+            g_last_variant = 100001;
+            return launch_tr_ring<false, 32, 4>(a, st);
         }
     }
     // 128x64 tiles when N is narrow or when 128x128 tiles would leave most of the 256 CUs (2 blocks each) idle

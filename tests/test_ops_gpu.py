@@ -51,8 +51,8 @@ def q(t, dtype):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('M,N,K', [(300, 168, 56), (1024, 256, 448), (640, 56, 224), (200, 84, 32), (128, 3584, 896)])
-def test_gemm_nt_epilogues(dtype, M, N, K):
+@pytest.mark.parametrize('M,N,K', [(300, 168, 56), (1024, 256, 448), (640, 56, 224), (200, 84, 32), (128, 3584, 896), (16400, 392, 224)])
+def test_gemm_nt_epilogues(dtype, M, N, K):      # the last shape: >= 384 tiles of 128 x 128 with K = 224 -> gemm_ring64_kernel
     x, w = q(rnd(M, K), dtype), q(rnd(N, K, seed=1) * 0.1, dtype)
     bias, res = rnd(N, seed=2), rnd(M, N, seed=3)
     rows_per = 100
@@ -103,10 +103,11 @@ def test_gemm_c28_padded_rows(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('M,N,K', [(300, 56, 168), (1024, 448, 256), (512, 224, 56), (12300, 508, 192)])
+@pytest.mark.parametrize('M,N,K', [(300, 56, 168), (1024, 448, 256), (512, 224, 56), (12300, 508, 192), (8200, 508, 224)])
 def test_gemm_nn_dx(dtype, M, N, K):
     """dX[M,N] = dY[M,K] @ W[K,N]  (W stored [K][N] -> w_trans).  The last shape (>= 384 tiles, K % 64 == 0) takes the bf16
-    kernel that reads W with transposing LDS reads (gemm_tr_kernel<false>), including its GELU' epilogue and bf16 output."""
+    kernel that reads W with transposing LDS reads (gemm_tr_ring_kernel<false, 64, ..>), including its GELU' epilogue and bf16 output;
+    the one after it (K = 224: a multiple of 32 only) the 32-deep form with X in 64-byte LDS rows (gemm_tr_ring_kernel<false, 32, 4>)."""
     dy, w = q(rnd(M, K), dtype), q(rnd(K, N, seed=1) * 0.1, dtype)
     ldn = (N + 7) // 8 * 8
     wp = torch.full((K, ldn), float('nan')); wp[:, :N] = w

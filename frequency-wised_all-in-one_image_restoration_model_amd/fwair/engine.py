@@ -579,9 +579,18 @@ def init_distributed():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # rehearsal aids (a one-GPU box): FW_DIST_DEVICE pins every rank to one device, FW_DIST_BACKEND=gloo replaces RCCL (which refuses
+    # two ranks on one device) -- the engine's multi-rank control flow (three-graph capture, overlapped bucket all-reduce, the ranks'
+    # agreement on the fallback) then runs for real, only the wire is different
+    if 'FW_DIST_DEVICE' in os.environ:
+        local = int(os.environ['FW_DIST_DEVICE'])
+    backend = os.environ.get('FW_DIST_BACKEND', 'nccl')
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world

@@ -1339,7 +1339,12 @@ int dispatch_trans(const GemmArgs& a, int xt, int wt, hipStream_t st) {
         static const int ring64 = getenv("FW_GEMM_RING64") ? atoi(getenv("FW_GEMM_RING64")) : 1;
         const int kt64 = 64 / TT<T>::SZ;
         if (ring64 && a.x_op == 0 && a.w_op == 0 && a.K % kt64 == 0 && a.kper % kt64 == 0 && (ring64 == 2 || (!whole && BN == 128)))
-            return launch_ring64<T, BN, 4>(a, st);
+        {
+            // three 16 KB stages = 48 KB: THREE workgroups per CU (160 VGPRs allow it) -- 19.4 -> 17.3 us against four stages at two
+            static const int ns64 = getenv("FW_GEMM_RING64_NS") ? atoi(getenv("FW_GEMM_RING64_NS")) : 3;
+            if (ns64 == 4) return launch_ring64<T, BN, 4>(a, st);
+            return launch_ring64<T, BN, 3>(a, st);
+        }
         static const int ring = getenv("FW_GEMM_RING") ? atoi(getenv("FW_GEMM_RING")) : 1;        // 0: gemm_kernel (one stage in flight)
         if (gx && gw && ring && a.kper % kt == 0) {
             // LDS per workgroup decides the residency: 2 stages of 128 x 128 = 64 KB -> 2 workgroups per CU (ring 1, default);

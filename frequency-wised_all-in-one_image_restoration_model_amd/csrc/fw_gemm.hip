@@ -745,7 +745,7 @@ FW_DEV uint4 frag_sw64(const char* tile, int row0) {
 }
 
 template <bool XT, int KT, int NS, bool PLAIN>
-__global__ __launch_bounds__(256) void gemm_tr_ring_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, (XT && KT == 32 && NS == 3) ? 3 : 2) void gemm_tr_ring_kernel(GemmArgs a) {
     using T = bf16raw;
     static_assert(NS >= 2 && NS <= 5, "ring depth");
     constexpr int WM = 4;
@@ -1432,7 +1432,10 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
         static const int ring = getenv("FW_GEMM_TR_RING") ? atoi(getenv("FW_GEMM_TR_RING")) : 1;     // 0: one stage in flight (gemm_tr_kernel)
         if (x_trans && (use_tr & 1) && ldx % 8 == 0) {
             g_last_variant = 100011;
-            if (ring == 1) return launch_tr_ring<true, 32, 4>(a, st);
+            // three 16 KB stages and a 3-waves-per-SIMD register budget (141 VGPRs, no spills): THREE workgroups per CU.  265.6 -> 266.9
+            // images/s against four stages at two workgroups (ring == 6 keeps that form); 155 -> 138 us at 65536 x 448 x 1024
+            if (ring == 1) return launch_tr_ring<true, 32, 3>(a, st);
+            if (ring == 6) return launch_tr_ring<true, 32, 4>(a, st);
             if (ring == 5) return launch_tr_ring<true, 64, 2>(a, st);
             if (ring == 2) return launch_tr_ring<true, 64, 3>(a, st);
             if (ring == 3) return launch_tr_ring<true, 64, 4>(a, st);

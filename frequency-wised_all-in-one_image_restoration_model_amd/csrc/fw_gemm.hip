@@ -745,7 +745,7 @@ FW_DEV uint4 frag_sw64(const char* tile, int row0) {
 }
 
 template <bool XT, int KT, int NS, bool PLAIN>
-__global__ __launch_bounds__(256, (XT && KT == 32 && NS == 3) ? 3 : 2) void gemm_tr_ring_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, (KT == 32 && NS == 3) ? 3 : 2) void gemm_tr_ring_kernel(GemmArgs a) {
     using T = bf16raw;
     static_assert(NS >= 2 && NS <= 5, "ring depth");
     constexpr int WM = 4;
@@ -1445,6 +1445,8 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
         static const long tr_min_tiles = getenv("FW_GEMM_TR_MIN_TILES") ? atol(getenv("FW_GEMM_TR_MIN_TILES")) : 200;   // 200..383 tiles: 77 -> 47 us at 4096 x 896 x 3584; below 200 the old kernel's 128 x 64 tiles fill more CUs
         if (!x_trans && (use_tr & 2) && !xsum && (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk >= tr_min_tiles) {
             g_last_variant = 100001;
+            static const int dx32 = getenv("FW_GEMM_TR_DX32") ? atoi(getenv("FW_GEMM_TR_DX32")) : 0;    // 1: plain epilogues, 2: all
+            if (dx32 && (dx32 == 2 || plain_epilogue(a))) return launch_tr_ring<false, 32, 3>(a, st);           // 48 KB: three workgroups per CU
             if (ring == 5) return launch_tr_ring<false, 64, 2>(a, st);
             // 3 stages = 96 KB = ONE workgroup per CU: fastest while the epilogue is a plain store.  An epilogue with an operand of its
             // own (GELU' input) keeps the CU's only 4 waves off the MFMAs for as long as the K loop took; 2 stages = 64 KB lets a
@@ -1462,7 +1464,7 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
         static const int r32 = getenv("FW_GEMM_TR_K32") ? atoi(getenv("FW_GEMM_TR_K32")) : 1;
         if (r32 && plain_epilogue(a)) {          // with the GELU' epilogue the round-1 tile kernel stays ahead (45.9 vs 49.9 us at 16384 x 896 x 224)
             g_last_variant = 100001;
-            return launch_tr_ring<false, 32, 4>(a, st);
+            return launch_tr_ring<false, 32, 3>(a, st);
         }
     }
     // 128x64 tiles when N is narrow or when 128x128 tiles would leave most of the 256 CUs (2 blocks each) idle

@@ -223,8 +223,12 @@ int ln_fwd_launch(const float* x, long ldx, const float* g, const float* b, void
 }
 static inline int ln_group(int C) { return C <= 32 ? 8 : (C <= 64 ? 16 : (C <= 128 ? 32 : 64)); }
 static inline int ln_rows_per_step(int C) { return C <= 256 ? 4 : (C <= 512 ? 2 : 1); }
+// Blocks of the backward pass: every block ends in a fold of its column partials (2 C LDS atomics per lane group, 2 C floats written
+// for fw_slab_reduce to re-read), so wide rows want FEW blocks that walk many rows -- rocprofv3 averages at caps 1024 / 512 / 256:
+// C = 896: 36.2 / 26.7 / 22.1 us, C = 448: 25.6 / 23.4 / 22.3 us, C = 224: 25.7 / 24.4 / 27.9 us, C <= 112: 46.5 / 47.4 / 57.8 us.
 static inline int ln_bwd_grid(int rows, int C) {
-    static const int cap = getenv("FW_LN_BWD_GRID") ? atoi(getenv("FW_LN_BWD_GRID")) : 1024;
+    static const int env_cap = getenv("FW_LN_BWD_GRID") ? atoi(getenv("FW_LN_BWD_GRID")) : 0;
+    const int cap = env_cap > 0 ? env_cap : (C > 256 ? 256 : (C > 128 ? 512 : 1024));
     return min(fw_cdiv(rows, 256 / ln_group(C) * ln_rows_per_step(C)), cap);
 }
 

@@ -34,6 +34,7 @@ def gemm(x, w, M, N, K, *, x_trans=False, w_trans=False, x_op=0, w_op=0, out=Non
 
 import os as _os
 _SPLITK_BLOCKS = int(_os.environ.get('FW_SPLITK_BLOCKS', '512'))       # tuning knob of pick_splitk (blocks in flight aimed at)
+_DGRAD_SPLIT_ROWS = int(_os.environ.get('FW_DGRAD_SPLIT_ROWS', '512'))   # reduction rows per slice of a split input gradient (ops.dgrad)
 
 
 def pick_splitk(M, N, K, dtype):
@@ -166,7 +167,9 @@ def dgrad(g, w, M, K, N, out, act=0, aux=None):
     """out[M,K] = epi(g[M,N] W[N,K])  (input gradient of a Linear).  A long reduction into a small output -- the 65536-wide
     mlp_head of the encoder: 32 output tiles, 1024 K-steps each -- is split over N into a slab of partial tiles."""
     tiles = ((M + 127) // 128) * ((K + 127) // 128)
-    sk = min(512 // max(tiles, 1), N // 2048) if act == 0 else 1
+    # fewer than 200 output tiles leave the chip to a handful of long K loops (1024 x 896 x 3584: 56 tiles, 56 steps each, 63 us):
+    # split the reduction so that one round of the chip is busy, at >= _DGRAD_SPLIT_ROWS reduction rows per slice
+    sk = min(512 // max(tiles, 1), N // _DGRAD_SPLIT_ROWS) if (act == 0 and tiles < 200) else 1
     if sk <= 1:
         gemm(g, w, M, K, N, w_trans=True, out=out, act=act, aux=aux)
         return

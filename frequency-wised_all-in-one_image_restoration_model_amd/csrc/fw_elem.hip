@@ -989,8 +989,10 @@ extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g
     const long n = (long)B * H * (W / SX) * (C / 4);
     const int nvg = (C / 4 + WG_VL - 1) / WG_VL;
     const long nst = (long)B * H * (W / SX);
-    int NSTRIP = 16;                               // strips per thread: fewer on small layers so that >= ~1000 blocks are in flight
-    while (NSTRIP > 2 && ((nst + (long)NSTRIP * WG_SL - 1) / ((long)NSTRIP * WG_SL)) * nvg < 768) NSTRIP >>= 1;   // every block ends in 1280 atomics: not too many blocks
+    static const int nstrip_max = getenv("FW_DWWG_NSTRIP") ? atoi(getenv("FW_DWWG_NSTRIP")) : 16;
+    int NSTRIP = nstrip_max;                       // strips per thread: fewer on small layers so that enough blocks are in flight
+    static const long wg_min_blocks = getenv("FW_DWWG_MIN_BLOCKS") ? atol(getenv("FW_DWWG_MIN_BLOCKS")) : 384;
+    while (NSTRIP > 2 && ((nst + (long)NSTRIP * WG_SL - 1) / ((long)NSTRIP * WG_SL)) * nvg < wg_min_blocks) NSTRIP >>= 1;   // every block ends in 1280 atomics: not too many blocks
     const long nsg = (nst + (long)NSTRIP * WG_SL - 1) / ((long)NSTRIP * WG_SL);
     const dim3 gridw((unsigned)(nsg * nvg));
     const bool tiled = dw_tiled() && H % DT_TY == 0 && (long)B * H * W * C >= dw_tiled_min();

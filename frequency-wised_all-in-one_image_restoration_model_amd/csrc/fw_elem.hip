@@ -545,20 +545,31 @@ __global__ __launch_bounds__(256) void inproj_fwd_kernel(const float* __restrict
         const int c = (int)(i % c4n) * 4; const long tok = i / c4n;
         const int x = (int)(tok % W); const int y = (int)((tok / W) % H); const long b = tok / ((long)W * H);
         f32x4 acc = *reinterpret_cast<const f32x4*>(sm + 27 * C + c);
+        // branch-free: the 27 taps are read from clamped coordinates (independent loads, issued together) and zeroed by a select --
+        // a load under a lane-varying branch is waited for before the next one is issued (137 us per launch with the branches)
+        float px[27];
 #pragma unroll
         for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const int yy = y + ky - 1;
-                if (yy < 0 || yy >= H) continue;
+                int yy = y + ky - 1; yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int xx = x + kx - 1;
-                    if (xx < 0 || xx >= W) continue;
-                    const float p = img[((b * 3 + ci) * H + yy) * W + xx];
-                    acc += *reinterpret_cast<const f32x4*>(sm + (ci * 9 + ky * 3 + kx) * C + c) * p;
+                    int xx = x + kx - 1; xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                    px[ci * 9 + ky * 3 + kx] = img[((b * 3 + ci) * H + yy) * W + xx];
                 }
             }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const bool yok = y + ky - 1 >= 0 && y + ky - 1 < H;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const bool ok = yok && x + kx - 1 >= 0 && x + kx - 1 < W;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)
+                    acc += *reinterpret_cast<const f32x4*>(sm + (ci * 9 + ky * 3 + kx) * C + c) * (ok ? px[ci * 9 + ky * 3 + kx] : 0.f);
+            }
+        }
         for (int e = 0; e < 4; ++e) acc[e] = lrelu_f(acc[e], slope);
         *reinterpret_cast<f32x4*>(out + tok * ldo + c) = acc;
     }

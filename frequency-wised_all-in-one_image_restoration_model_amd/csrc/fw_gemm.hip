@@ -1428,7 +1428,9 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
     // bf16 products whose W is stored [K][N] (weight gradients: X token-major too; input gradients: X k-contiguous), whole
     // 64-deep K steps: W (and X) tiles go to LDS as they are and are read with transposing LDS reads (gemm_tr_kernel)
     static const int use_tr = getenv("FW_GEMM_TR") ? atoi(getenv("FW_GEMM_TR")) : 3;
-    static const int tr_small_n = getenv("FW_GEMM_TR_SMALL_N") ? atoi(getenv("FW_GEMM_TR_SMALL_N")) : 0;   // 1: weight gradients with N <= 64 too
+    // weight gradients with N <= 64 (the C = 28 / 56 stages: 56 x 28 x 786432, ...) on the ring kernel too: its 128 x 128 tile is mostly
+    // masked there, but the long reduction is what costs -- 62.3 -> 48.2, 57.3 -> 34.7, 28.2 -> 17.4 us against the 128 x 64 tile kernel
+    static const int tr_small_n = getenv("FW_GEMM_TR_SMALL_N") ? atoi(getenv("FW_GEMM_TR_SMALL_N")) : 1;
     if (dtype == FW_DT_BF16 && w_trans && x_op == 0 && w_op == 0 && (N > 64 || (tr_small_n && x_trans && N >= 8)) && K % 64 == 0 && a.kper % 64 == 0 && ldw % 8 == 0) {
         static const int ring = getenv("FW_GEMM_TR_RING") ? atoi(getenv("FW_GEMM_TR_RING")) : 1;     // 0: one stage in flight (gemm_tr_kernel)
         if (x_trans && (use_tr & 1) && ldx % 8 == 0) {

@@ -1465,7 +1465,7 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
     if (dtype == FW_DT_BF16 && w_trans && !x_trans && x_op == 0 && w_op == 0 && N > 64 && K % 64 != 0 && K % 32 == 0 && ldw % 8 == 0 && !xsum
         && splitk == 1 && (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) >= 200) {
         static const int r32 = getenv("FW_GEMM_TR_K32") ? atoi(getenv("FW_GEMM_TR_K32")) : 1;
-        if (r32 && plain_epilogue(a)) {          // with the GELU' epilogue the round-1 tile kernel stays ahead (45.9 vs 49.9 us at 16384 x 896 x 224)
+        if (r32 && (r32 == 2 || plain_epilogue(a))) {          // with the GELU' epilogue the round-1 tile kernel stays ahead (45.9 vs 49.9 us at 16384 x 896 x 224)
             g_last_variant = 100001;
             return launch_tr_ring<false, 32, 3>(a, st);
         }

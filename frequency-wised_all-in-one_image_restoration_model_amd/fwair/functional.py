@@ -416,7 +416,7 @@ class QKVFn(torch.autograd.Function):
         dx = act_empty(M, K, x.dtype, x.device)
         if w3 is not None and config.direct_grads and 'gw' in fused:
             ops.wgrad(dbuf[:, :3 * C], x, 3 * C, K, M, fused['gw'], fused['gb'], defer=True)
-            ops.gemm(dbuf[:, :3 * C], w3, M, K, 3 * C, w_trans=True, out=dx)
+            ops.dgrad(dbuf[:, :3 * C], w3, M, K, 3 * C, dx)          # split over the 3C reduction when the output has few tiles
             return dx, None, None, None, None, None
         dq, dkv = dbuf[:, :C], dbuf[:, Cp:]
         dwq, dbq = _wgrad(dq, x, C, K, M, wq, ctx.bq)

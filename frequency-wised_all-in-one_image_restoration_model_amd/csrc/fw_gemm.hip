@@ -605,6 +605,100 @@ FW_DEV void tile_epilogue(const GemmArgs& a, const f32x4 (&acc)[4][WM], int m_bl
             }
         }
     } else {
+        // Lean forms of the three epilogues that carry most of a step's non-plain launches: straight-line code, decided ONCE per
+        // wave (the conditions are kernel arguments) instead of ~10 run-time switches per quad in the general form below.
+        const bool tw = sizeof(T) == 2 && a.alpha == 1.0f && !a.out_f32 && !a.rowscale && !a.residual && !a.accumulate;
+        if (tw && a.act == 2 && !a.C2) {                       // (A) dX = (dY W) o GELU'(aux): fc2's input gradient
+            auto fetchA = [&](uint2 (&ext)[4], int mt) {
+                const int m = m_blk + wm0 + mt * 16 + (l & 15);
+                const T* ap = reinterpret_cast<const T*>(a.aux) + (long)(m < a.M ? m : a.M - 1) * a.ldaux;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+                    ext[nt] = *reinterpret_cast<const uint2*>(ap + (n0 < a.N ? n0 : 0));
+                }
+            };
+            auto applyA = [&](const uint2 (&ext)[4], int mt) {
+                const int m = m_blk + wm0 + mt * 16 + (l & 15);
+                if (m >= a.M) return;
+                T* cp = reinterpret_cast<T*>(a.C) + (long)m * a.ldc;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+                    if (n0 >= a.N) continue;
+                    const f32x4 v = acc[nt][mt] + bias4[nt];
+                    const float x0 = __uint_as_float(ext[nt].x << 16), x1 = __uint_as_float(ext[nt].x & 0xffff0000u);
+                    const float x2 = __uint_as_float(ext[nt].y << 16), x3 = __uint_as_float(ext[nt].y & 0xffff0000u);
+                    *reinterpret_cast<uint2*>(cp + n0) = make_uint2(pack_bf2(v[0] * gelu_grad_poly(x0), v[1] * gelu_grad_poly(x1)),
+                                                                    pack_bf2(v[2] * gelu_grad_poly(x2), v[3] * gelu_grad_poly(x3)));
+                }
+            };
+            uint2 ea[4], eb[4];
+            fetchA(ea, 0);
+#pragma unroll
+            for (int mt = 0; mt < WM; mt += 2) {
+                if (mt + 1 < WM) fetchA(eb, mt + 1);
+                applyA(ea, mt);
+                if (mt + 1 < WM) {
+                    if (mt + 2 < WM) fetchA(ea, mt + 2);
+                    applyA(eb, mt + 1);
+                }
+            }
+            return;
+        }
+        if (tw && a.act == 0 && a.C2) {                        // (B) h = x W^T + b and its GELU twin: fc1 forward
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt) {
+                const int m = m_blk + wm0 + mt * 16 + (l & 15);
+                if (m >= a.M) continue;
+                T* cp = reinterpret_cast<T*>(a.C) + (long)m * a.ldc;
+                T* c2 = reinterpret_cast<T*>(a.C2) + (long)m * a.ldc2;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+                    if (n0 >= a.N) continue;
+                    const f32x4 v = acc[nt][mt] + bias4[nt];
+                    *reinterpret_cast<uint2*>(cp + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    *reinterpret_cast<uint2*>(c2 + n0) = make_uint2(pack_bf2(gelu_poly(v[0]), gelu_poly(v[1])), pack_bf2(gelu_poly(v[2]), gelu_poly(v[3])));
+                }
+            }
+            return;
+        }
+        if (a.act == 0 && a.residual && a.out_f32 && !a.C2 && a.alpha == 1.0f && !a.accumulate && a.splitk == 1 && a.c_zstride == 0) {
+            // (C) y = res + rs * (x W^T + b), f32 out: the attention projection and fc2 forward (DropPath row scale optional)
+            auto fetchC = [&](f32x4 (&ext)[4], int mt) {
+                const int m = m_blk + wm0 + mt * 16 + (l & 15);
+                const float* rp = a.residual + (long)(m < a.M ? m : a.M - 1) * a.ldr;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+                    ext[nt] = *reinterpret_cast<const f32x4*>(rp + (n0 < a.N ? n0 : 0));
+                }
+            };
+            auto applyC = [&](const f32x4 (&ext)[4], int mt) {
+                const int m = m_blk + wm0 + mt * 16 + (l & 15);
+                if (m >= a.M) return;
+                const float rs = a.rowscale ? a.rowscale[m / a.rows_per_scale] : 1.0f;
+                float* cp = reinterpret_cast<float*>(a.C) + (long)m * a.ldc;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+                    if (n0 < a.N) *reinterpret_cast<f32x4*>(cp + n0) = (acc[nt][mt] + bias4[nt]) * rs + ext[nt];
+                }
+            };
+            f32x4 ea[4], eb[4];
+            fetchC(ea, 0);
+#pragma unroll
+            for (int mt = 0; mt < WM; mt += 2) {
+                if (mt + 1 < WM) fetchC(eb, mt + 1);
+                applyC(ea, mt);
+                if (mt + 1 < WM) {
+                    if (mt + 2 < WM) fetchC(ea, mt + 2);
+                    applyC(eb, mt + 1);
+                }
+            }
+            return;
+        }
         // the row-dependent operand (GELU' input / residual) of 16-row group mt + 1 is requested before group mt is applied and
         // stored: one exposed memory latency per tile instead of one per group.  (Requesting the whole wave tile up front -- 16
         // loads, 64 registers -- measured SLOWER than group-by-group: 135 -> 145 us at 16384 x 1792 x 448.)
@@ -1464,8 +1558,8 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
     // the same input-gradient product with K a multiple of 32 only (K = 224, 336 is not): 32-deep steps, X in 64-byte rows
     if (dtype == FW_DT_BF16 && w_trans && !x_trans && x_op == 0 && w_op == 0 && N > 64 && K % 64 != 0 && K % 32 == 0 && ldw % 8 == 0 && !xsum
         && splitk == 1 && (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) >= 200) {
-        static const int r32 = getenv("FW_GEMM_TR_K32") ? atoi(getenv("FW_GEMM_TR_K32")) : 1;
-        if (r32 && (r32 == 2 || plain_epilogue(a))) {          // with the GELU' epilogue the round-1 tile kernel stays ahead (45.9 vs 49.9 us at 16384 x 896 x 224)
+        static const int r32 = getenv("FW_GEMM_TR_K32") ? atoi(getenv("FW_GEMM_TR_K32")) : 2;     // 1: plain epilogues only
+        if (r32 && (r32 == 2 || plain_epilogue(a))) {          // with the lean GELU' epilogue: 44.4 -> 34.2 us at 16384 x 896 x 224 against the round-1 tile kernel
             g_last_variant = 100001;
             return launch_tr_ring<false, 32, 3>(a, st);
         }

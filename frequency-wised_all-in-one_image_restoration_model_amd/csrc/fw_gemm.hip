@@ -1542,8 +1542,12 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
         static const long tr_min_tiles = getenv("FW_GEMM_TR_MIN_TILES") ? atol(getenv("FW_GEMM_TR_MIN_TILES")) : 200;   // 200..383 tiles: 77 -> 47 us at 4096 x 896 x 3584; below 200 the old kernel's 128 x 64 tiles fill more CUs
         if (!x_trans && (use_tr & 2) && !xsum && (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk >= tr_min_tiles) {
             g_last_variant = 100001;
-            static const int dx32 = getenv("FW_GEMM_TR_DX32") ? atoi(getenv("FW_GEMM_TR_DX32")) : 0;    // 1: plain epilogues, 2: all
-            if (dx32 && (dx32 == 2 || plain_epilogue(a))) return launch_tr_ring<false, 32, 3>(a, st);           // 48 KB: three workgroups per CU
+            // plain store and MORE blocks than CUs: the 32-deep form (48 KB, 126 VGPRs: three workgroups per CU) -- co-residency pays
+            // once a CU has more than one block to run (16384 x 448 x 1792: 53.1 -> 45.1 us, 512 blocks); with at most one block per
+            // CU the 64-deep three-stage ring stays ahead (4096 x 896 x 3584: 49.3 vs 54.4 us, 224 blocks).  0: never, 2: always
+            static const int dx32 = getenv("FW_GEMM_TR_DX32") ? atoi(getenv("FW_GEMM_TR_DX32")) : 1;
+            if (dx32 && plain_epilogue(a) && (dx32 == 2 || (long)fw_cdiv(M, 128) * fw_cdiv(N, 128) * splitk > 256))
+                return launch_tr_ring<false, 32, 3>(a, st);
             if (ring == 5) return launch_tr_ring<false, 64, 2>(a, st);
             // 3 stages = 96 KB = ONE workgroup per CU: fastest while the epilogue is a plain store.  An epilogue with an operand of its
             // own (GELU' input) keeps the CU's only 4 waves off the MFMAs for as long as the K loop took; 2 stages = 64 KB lets a

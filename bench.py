@@ -32,35 +32,31 @@ PEAK_HBM = 8.0e12
 PEAK_FOR = {'bf16': PEAK_BF16, 'f32': PEAK_F32_MFMA}
 
 
-def synth_batch(B, size, sigma, seed, device):
-    """low-frequency cosines + rectangles, uint8-quantised; noise as utils/dataset_utils.py:126."""
-    rs = np.random.RandomState(seed)
-    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
-    clean = np.zeros((B, 3, size, size), np.float32)
-    for b in range(B):
-        for c in range(3):
-            img = np.zeros((size, size), np.float32)
-            for _ in range(8):
-                fx, fy, ph, a = rs.uniform(0, 4), rs.uniform(0, 4), rs.uniform(0, 6.28), rs.uniform(0.2, 1)
-                img += a * np.cos(6.2832 * (fx * xx + fy * yy) + ph)
-            for _ in range(4):
-                x0, y0 = rs.randint(0, size - 8, 2)
-                w, h = rs.randint(8, size // 2, 2)
-                img[y0:y0 + h, x0:x0 + w] += rs.uniform(-1, 1)
-            img = (img - img.min()) / max(img.max() - img.min(), 1e-6)
-            clean[b, c] = np.round(img * 255) / 255
-    def noisy():
-        return np.clip(clean * 255 + sigma * rs.randn(*clean.shape), 0, 255).astype(np.uint8).astype(np.float32) / 255
-    t = lambda a: torch.from_numpy(a).to(device)
-    return t(clean), t(noisy()), t(noisy())
+from fwair.synthetic import synth_batch      # noqa: E402  (SURVEY.md 8(d) generator, shared with train_ddp.py)
 
 
-def make_opt(batch, dtype, patch=128):
+def make_opt(batch, dtype, patch=128, encoder='Uformer', tasks=None):
     import types
-    return types.SimpleNamespace(L=3, encoder_dim=256, encoder_embed_dim=28, embed_dim=56, batch_size=batch, patch_size=patch,
-                                 degradation_embedding_method=['all_3_bands'], encoder_msa_type='freq', contrast_loss_weight=0.6,
-                                 encoder_type='Uformer', decoder_type='Uformer', debug_mode=False, frequency_decompose_type='none',
-                                 learnable_modulator=False, compute_dtype=dtype, de_type=['denoising_25'] * batch)
+    o = types.SimpleNamespace(L=3, encoder_dim=256, encoder_embed_dim=28, embed_dim=56, batch_size=batch, patch_size=patch,
+                              degradation_embedding_method=['all_3_bands'], encoder_msa_type='freq', contrast_loss_weight=0.6,
+                              encoder_type='Uformer', decoder_type='Uformer', debug_mode=False, frequency_decompose_type='none',
+                              learnable_modulator=False, compute_dtype=dtype, de_type=[(tasks or ['denoising_25'])[i % len(tasks or [1])]
+                                                                                        for i in range(batch)])
+    if encoder == 'ViT':          # BASELINE configs[4]: ViT encoder (N = (patch/16)^2 tokens) + plain Uformer decoder (option.py:80-101: encoder_dim 3)
+        o.encoder_type, o.encoder_dim, o.degradation_embedding_method, o.out_channels, o.batch_wise_decompose = 'ViT', 3, ['None'], 3, False
+    return o
+
+
+def flop_per_image_step(encoder, patch):
+    """Dense-contraction FLOPs of one training step per image: 3 x (query encoder + decoder) + key-encoder forward."""
+    px = (patch / 128) ** 2
+    dec = 138.66e9 * px
+    if encoder == 'ViT':
+        n = (patch // 16) ** 2
+        enc = 12 * (2 * n * (768 * 2304 + 768 * 768 + 2 * 768 * 3072) + 4 * n * n * 768) + 2 * n * 768 * 768 + 2 * n * 768 * 768
+    else:
+        enc = 34.72e9 * px
+    return 3 * (enc + dec) + enc
 
 
 def gemm_profile(engine, batch, reps=8):
@@ -394,30 +390,74 @@ def host_threads():
     return max(1, min(n, 16))
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves -- one fresh child process per GPU
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1 -- BEFORE this process has made any HIP call
+    (importing torch does not initialise the device), wait for them and leave with the worst exit code.  Rank 0's stdout (the
+    one JSON line) is ours; the other ranks' stdout goes to stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), FW_BENCH_CHILD='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:                    # a dead rank leaves the others waiting in a collective: stop them
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for q in procs:
+            q.kill()
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--patch-size', type=int, default=128, help='side of the training patch (128 = the headline config; 256 = SURVEY 8f-4)')
+    ap.add_argument('--encoder', default='Uformer', choices=['Uformer', 'ViT'], help='ViT = BASELINE configs[4] (with --patch-size 256)')
+    ap.add_argument('--tasks', default='denoise', choices=['denoise', 'allinone'], help='allinone = BASELINE configs[2]/[3]: 5 tasks cycled over the batch')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        launch_ranks(args.gpus)                               # never returns
 
     from fwair import engine as E
     rank, local, world = E.init_distributed()
-    assert world == max(1, args.gpus) or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert world == max(1, args.gpus), f'--gpus {args.gpus} but WORLD_SIZE={world}'
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     from net.model import AirNet
     torch.manual_seed(1234)
-    opt = make_opt(args.batch, args.dtype, args.patch_size)
+    tasks = ['denoising_15', 'denoising_25', 'denoising_50', 'deraining', 'dehazing'] if args.tasks == 'allinone' else None
+    opt = make_opt(args.batch, args.dtype, args.patch_size, args.encoder, tasks)
     net = AirNet(opt).to(dev).train()
     eng = E.TrainEngine(net, lr=2e-4, contrast_loss_weight=0.6, use_graph=not args.no_graph)
-    batch = synth_batch(args.batch, args.patch_size, 25, 1234 + rank, dev)
+    if tasks is None:
+        batch = synth_batch(args.batch, args.patch_size, 25, 1234 + rank, dev)
+    else:                                                    # BASELINE configs[2] / [3]: denoise 15 / 25 / 50, derain, dehaze cycled over the batch
+        from fwair.synthetic import synth_task_batch
+        batch = synth_task_batch(args.batch, args.patch_size, tasks, 1234 + rank, dev)
     clean, xq, xk = batch
     data = (xq, xk, clean)
 
@@ -466,14 +506,17 @@ def main():
         'metric': f'training images/sec @{args.patch_size}x{args.patch_size}', 'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[1]: Uformer encoder+decoder (all_3_bands, L=3, freq MSA), denoise sigma=25, '
-                               f'{args.patch_size}x{args.patch_size}, phase-2 train step (fwd+bwd+Adam, DropPath on)', 'per_gpu_batch': args.batch,
+        'config': {'workload': (('BASELINE configs[4]: ViT encoder (N = %d tokens, Dropout 0.1 on) + plain Uformer decoder, ' % ((args.patch_size // 16) ** 2)
+                                 if args.encoder == 'ViT' else
+                                 ('BASELINE configs[2]: ' if tasks else 'BASELINE configs[1]: ') + 'Uformer encoder+decoder (all_3_bands, L=3, freq MSA), ')
+                                + ('all-in-one (denoise 15/25/50 + derain + dehaze), ' if tasks else 'denoise sigma=25, ')
+                                + f'{args.patch_size}x{args.patch_size}, phase-2 train step (fwd+bwd+Adam, DropPath on)'), 'per_gpu_batch': args.batch,
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'hip_graph': graph_ok},
         'loss': {'total': loss[0], 'l1': loss[1], 'contrast': loss[2]},
         'pcie_inclusive_value': round(args.batch * world / (dt / args.steps + h2d), 2), 'h2d_ms_per_step': round(h2d * 1e3, 3),
     }
     peak = PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32_MFMA
-    res['step_mfma_fraction'] = round(ips / world * FLOP_PER_IMAGE_STEP * (args.patch_size / 128) ** 2 / peak, 5)   # FLOPs scale with pixels
+    res['step_mfma_fraction'] = round(ips / world * flop_per_image_step(args.encoder, args.patch_size) / peak, 5)
     if rank == 0 and world == 1 and not args.no_profile:
         log('timing every distinct GEMM launch of the step (HIP events around captured replays) ...')
         agg, launches = gemm_profile(eng, data)

@@ -131,6 +131,24 @@ FW_DEV float wave_max(float v) {
     return v;
 }
 
+// ---------------------------------------------------------------- counter-based Bernoulli masks (nn.Dropout, encoder_ViT.py:31-33,67,73,158)
+// A mask element is a pure function of (seed, site, element index): nothing is stored between forward and backward, the
+// backward pass re-derives the forward's mask, and the CPU oracle (oracle/dropout_hash.py) evaluates the same integers.
+// seed: one u32 in device memory, advanced once per training step (fw_rng_tick); site: one id per Dropout module call site.
+FW_DEV unsigned fw_hash32(unsigned x) {                       // "lowbias32" integer finaliser
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+FW_DEV unsigned fw_site_key(unsigned seed, unsigned site) { return fw_hash32(seed ^ fw_hash32(site * 0x9E3779B9U + 0x7F4A7C15U)); }
+// keep with probability 1 - thresh / 2^32
+FW_DEV bool fw_keep(unsigned key, unsigned long long idx, unsigned thresh) {
+    return fw_hash32(fw_hash32((unsigned)idx ^ key) + (unsigned)(idx >> 32)) >= thresh;
+}
+static inline unsigned fw_drop_thresh(float p) {
+    const double t = (double)p * 4294967296.0;
+    return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
+}
+
 // ---------------------------------------------------------------- MFMA on one 64-byte k-chunk
 template <typename T> FW_DEV void mma_chunk(f32x4& acc, const uint4& a, const uint4& b);
 template <> FW_SPEC void mma_chunk<bf16raw>(f32x4& acc, const uint4& a, const uint4& b) {

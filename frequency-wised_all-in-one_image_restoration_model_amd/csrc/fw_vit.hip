@@ -131,9 +131,56 @@ __global__ void small_linear_bwd_kernel(const float* __restrict__ dy, const floa
         }
     }
 }
+
+// ---- nn.Dropout call sites of the ViT (encoder_ViT.py:31,33,73,158,189) as counter-based masks (fw_common.h: fw_keep) -----------
+// mode 0: y = drop(x)                          f32 -> f32   (backward of modes 1 and 4: the same mask on the gradient)
+// mode 1: y = res + drop(x)                    f32          (to_out / FeedForward output + residual stream)
+// mode 2: y = drop(gelu(x))                    T -> T       (FeedForward hidden: GELU, Dropout)
+// mode 3: y = drop(x) * gelu'(aux)             T -> T       (backward of mode 2)
+// mode 4: y = drop(x + aux[i % period])        f32          (x += pos_embedding; emb dropout)
+// thresh == 0 (eval / p = 0) keeps everything.  The element index i is the flat index of the (contiguous) tensor.
+template <typename T>
+__global__ void dropout_kernel(int mode, const void* __restrict__ xv, const void* __restrict__ auxv, const float* __restrict__ res,
+                               void* __restrict__ yv, long n, long period, const unsigned* __restrict__ seed, unsigned site, unsigned thresh,
+                               float inv_keep) {
+    const unsigned key = thresh ? fw_site_key(seed[0], site) : 0u;
+    for (long i = gtid(); i < n; i += gstride()) {
+        const float m = (!thresh || fw_keep(key, (unsigned long long)i, thresh)) ? inv_keep : 0.f;
+        if (mode == 2 || mode == 3) {
+            const T* x = (const T*)xv; T* y = (T*)yv;
+            const float v = TT<T>::ld(x + i);
+            TT<T>::st(y + i, mode == 2 ? gelu_t<T>(v) * m : v * m * gelu_grad_t<T>(TT<T>::ld((const T*)auxv + i)));
+        } else {
+            const float* x = (const float*)xv; float* y = (float*)yv;
+            if (mode == 0) y[i] = x[i] * m;
+            else if (mode == 1) y[i] = res[i] + x[i] * m;
+            else y[i] = (x[i] + ((const float*)auxv)[i % period]) * m;
+        }
+    }
+}
+__global__ void rng_tick_kernel(unsigned* seed) { if (gtid() == 0) seed[0] += 1u; }
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+extern "C" int fw_dropout(int mode, int dtype, const void* x, const void* aux, const float* res, void* y, long n, long period, const void* seed,
+                          int site, float p, void* stream) {
+    FW_CHECK_ARG(x && y && n > 0 && mode >= 0 && mode <= 4 && p >= 0.f && p < 1.f && (p == 0.f || seed));
+    FW_CHECK_ARG((mode != 1 || res) && (mode != 3 || aux) && (mode != 4 || (aux && period > 0)));
+    const unsigned thresh = p > 0.f ? fw_drop_thresh(p) : 0u;
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    if (dtype == FW_DT_BF16 && (mode == 2 || mode == 3))
+        hipLaunchKernelGGL((dropout_kernel<bf16raw>), dim3(grid_for(n)), dim3(TPB), 0, ST, mode, x, aux, res, y, n, period, (const unsigned*)seed,
+                           (unsigned)site, thresh, ik);
+    else
+        hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid_for(n)), dim3(TPB), 0, ST, mode, x, aux, res, y, n, period, (const unsigned*)seed,
+                           (unsigned)site, thresh, ik);
+    FW_LAUNCH_RET();
+}
+extern "C" int fw_rng_tick(void* seed, void* stream) {
+    FW_CHECK_ARG(seed);
+    hipLaunchKernelGGL(rng_tick_kernel, dim3(1), dim3(64), 0, ST, (unsigned*)seed);
+    FW_LAUNCH_RET();
+}
 extern "C" int fw_add_bcast(const float* x, const float* p, float* out, long n, long period, void* stream) {
     FW_CHECK_ARG(x && p && out && n > 0 && period > 0);
     hipLaunchKernelGGL(add_bcast_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, x, p, out, n, period);

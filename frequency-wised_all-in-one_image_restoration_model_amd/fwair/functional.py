@@ -60,6 +60,14 @@ def shadow(param, kind='plain'):
     stamp = (param._version, config.shadow_epoch, p.data_ptr())
     if ent is not None and key in ent and ent[key][0] == stamp:
         return ent[key][1]
+    if ent is not None and key in ent and ent[key][2] is not None and ent[key][2][0].data_ptr() == p.data_ptr():
+        # stale stamp, same parameter storage: re-derive INTO the buffer the entry already owns.  A captured HIP graph (and the
+        # fw_permute3_multi table of refresh_shadows) holds this buffer's address; allocating a new one would leave the graph
+        # reading freed allocator memory after the next eager forward (an eval between graph replays).
+        _, out, recipe = ent[key]
+        ops.permute3(recipe[0], out, recipe[1], recipe[2])
+        ent[key] = (stamp, out, recipe)
+        return out
     recipe = None                                   # (src f32 view, (d0, d1, d2), output strides): out[a*s0 + b*s1 + c*s2] = src[a][b][c]
     if kind == 'plain':
         n, k = p.shape[0], p[0].numel()
@@ -82,7 +90,9 @@ def shadow(param, kind='plain'):
         # linear2 [roundup(C, 16) + 1][4C] with zero rows (one spare row: the last chunk's fragment reads run 16 elements on)
         n, k = p.shape
         rows, cols = (n, (k + 31) // 32 * 32) if kind == 'leff1' else ((n + 15) // 16 * 16 + 1, k)
-        out = torch.zeros((rows, cols), dtype=torch.bfloat16, device=p.device)
+        prev = ent[key][1] if ent is not None and key in ent else None
+        out = prev if prev is not None and prev.shape == (rows, cols) and prev.device == p.device else \
+            torch.zeros((rows, cols), dtype=torch.bfloat16, device=p.device)     # re-cast in place: captured graphs hold the address
         call('fw_cast_rows', 1, p, k, out, cols, n, k, None, 1)
     else:
         raise ValueError(kind)
@@ -149,6 +159,7 @@ def shadow_qkv(wq, bq, wkv, bkv):
 
 
 _refresh_tables = {}          # which -> (signature, device table, device prefix, num, total blocks)
+_retired_tables = []          # superseded tables, kept alive: captured graphs hold their addresses
 
 
 def refresh_shadows(which='all', only_ids=None, restamp_others=False):
@@ -159,15 +170,17 @@ def refresh_shadows(which='all', only_ids=None, restamp_others=False):
     restamp_others: the remaining entries are known to be unchanged and are marked fresh without a launch.
     The table of a set is built on first use OUTSIDE stream capture; inside a capture an unseen set is left to the per-entry path."""
     items, stamps = [], []
-    for pid, (ref, ent) in _shadow.items():
+    for pid, (ref, ent) in list(_shadow.items()):                    # a weakref callback may pop entries while we walk (cyclic GC)
         param = ref()
         if param is None:
             continue
         mine = only_ids is None or pid in only_ids
-        for key, (stamp, out, recipe) in ent.items():
+        for key, (stamp, out, recipe) in list(ent.items()):
             if recipe is None or not (mine or restamp_others):
                 continue
-            fresh = (param._version, config.shadow_epoch, param.data_ptr())
+            # entries that are only re-stamped keep their recorded tensor version: an in-place update that did not go through
+            # the engine (load_state_dict, a torch optimizer) still shows as stale and is re-derived by shadow()
+            fresh = (param._version if mine else stamp[0], config.shadow_epoch, param.data_ptr())
             if fresh[2] != recipe[0].data_ptr():
                 continue                                             # the parameter moved (e.g. .to(device)): let shadow() rebuild it
             stamps.append((ent, key, fresh, out, recipe))
@@ -180,13 +193,18 @@ def refresh_shadows(which='all', only_ids=None, restamp_others=False):
         cached = _refresh_tables.get(which)
         if cached is None or cached[0] != sig:
             if torch.cuda.is_current_stream_capturing():
-                return                                               # no host -> device table upload inside a capture
+                # no host -> device table upload inside a capture, and a graph without the refresh would replay on operand
+                # copies frozen at capture time: fail the capture loudly (the engine warms up eagerly first, which builds it)
+                raise RuntimeError(f'fwair: refresh_shadows({which!r}) has no device table for this parameter set inside a stream '
+                                   'capture; run one eager step before capturing')
             offs, total = [0], 0
             for it in items:
                 total += (it[2] * it[3] * it[4] + 1023) // 1024
                 offs.append(total)
             dev = stamps[0][3].device
             cached = (sig, torch.tensor(items, dtype=torch.int64).to(dev), torch.tensor(offs, dtype=torch.int64).to(dev), len(items), total)
+            if _refresh_tables.get(which) is not None:
+                _retired_tables.append(_refresh_tables[which])       # a captured graph may still launch from the superseded table
             _refresh_tables[which] = cached
         call('fw_permute3_multi', cached[1], cached[2], cached[3], cached[4])
     for ent, key, fresh, out, recipe in stamps:
@@ -855,6 +873,107 @@ class LfsLambdaFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# nn.Dropout as counter-based masks (csrc/fw_common.h: fw_keep): one u32 seed per device, advanced once per training step
+# ---------------------------------------------------------------------------------------------------------------
+_rng = {}                     # device -> int32 [1] tensor holding the u32 seed
+_rng_frozen = [False]
+
+
+def dropout_seed(device):
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == 'cuda' else 0))
+    t = _rng.get(key)
+    if t is None:
+        if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('fwair: the dropout seed must exist before a stream capture (run one eager step first)')
+        v = int(torch.initial_seed()) & 0x7fffffff
+        t = _rng[key] = torch.tensor([v], dtype=torch.int32, device=device)
+    return t
+
+
+def set_dropout_seed(value, device, frozen=False):
+    """Tests: a known seed; frozen = the per-step tick is disabled, so forward, backward and the oracle see `value`."""
+    dropout_seed(device).fill_(int(value) - (1 << 32) if int(value) >= (1 << 31) else int(value))
+    _rng_frozen[0] = bool(frozen)
+
+
+def dropout_tick(device):
+    device = torch.device(device)
+    if _rng_frozen[0] or device.type != 'cuda':
+        return
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key in _rng:
+        call('fw_rng_tick', _rng[key])
+
+
+class DropoutFn(torch.autograd.Function):
+    """y = drop(x) on a contiguous f32 tensor (site, p); the backward pass re-derives the mask."""
+
+    @staticmethod
+    def forward(ctx, x, site, p):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        seed = dropout_seed(x.device)
+        call('fw_dropout', 0, 0, x, None, None, y, x.numel(), 1, seed, site, p)
+        ctx.cfg = (site, p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        site, p, seed = ctx.cfg
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(dy)
+        call('fw_dropout', 0, 0, dy, None, None, dx, dy.numel(), 1, seed, site, p)
+        return dx, None, None
+
+
+class DropAddFn(torch.autograd.Function):
+    """y = res + drop(x): a branch's output Dropout followed by the residual add (encoder_ViT.py:33,73,112-116); f32 [M, C]."""
+
+    @staticmethod
+    def forward(ctx, x, res, site, p):
+        x, res = x.contiguous(), res.contiguous()
+        y = torch.empty_like(res)
+        seed = dropout_seed(x.device)
+        call('fw_dropout', 1, 0, x, None, res, y, x.numel(), 1, seed, site, p)
+        ctx.cfg = (site, p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        site, p, seed = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        call('fw_dropout', 0, 0, dy, None, None, dx, dy.numel(), 1, seed, site, p)
+        return dx, dy, None, None
+
+
+class GeluDropFn(torch.autograd.Function):
+    """g = drop(GELU(h)) on a contiguous T tensor (FeedForward: nn.GELU, nn.Dropout -- encoder_ViT.py:30-31)."""
+
+    @staticmethod
+    def forward(ctx, h, site, p):
+        assert h.is_contiguous()
+        g = torch.empty_like(h)
+        seed = dropout_seed(h.device)
+        call('fw_dropout', 2, dt(h.dtype), h, None, None, g, h.numel(), 1, seed, site, p)
+        ctx.save_for_backward(h)
+        ctx.cfg = (site, p, seed)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        (h,) = ctx.saved_tensors
+        site, p, seed = ctx.cfg
+        dg = dg.contiguous()
+        if dg.dtype != h.dtype:
+            dg = dg.to(h.dtype)
+        dh = torch.empty_like(h)
+        call('fw_dropout', 3, dt(h.dtype), dg, h, None, dh, h.numel(), 1, seed, site, p)
+        return dh, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # DropPath row scales (timm semantics: floor(keep + U) / keep per sample)
 # ---------------------------------------------------------------------------------------------------------------
 _dp_override = None
@@ -914,6 +1033,7 @@ def droppath_begin(device, key='step'):
         pool = _dp_pools[key] = _DropPathPool()
     _dp_current[0] = pool
     pool.begin(device)
+    dropout_tick(device)                                   # a new training step: new Dropout masks (no-op without a Dropout user)
 
 
 def droppath_scale(name, nsamples, rate, training, device):

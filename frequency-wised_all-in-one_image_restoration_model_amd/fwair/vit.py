@@ -3,18 +3,22 @@ kernels: same class / attribute names (`to_patch_embedding`, `pos_embedding`, `t
 `mlp`, `depth`), constructor `(opt)`, return value `(fea, [out], inter)` and state_dict keys (tests/golden/schema.json
 `vit_uformer`, dumped from the reference).
 
-Token stream: f32 [B*N, 768] (the residual stream, as in the Uformer blocks); GEMM / attention operands T.  One image is one
-attention "window" of N = (S/16)^2 tokens: at 128x128 N = 64 and the window-attention kernel runs it as a single 8x8 window per
-image with head_dim 64, 12 heads and a zero relative-position table.
+Token stream: f32 [B*N, 768] (the residual stream, as in the Uformer blocks); GEMM / attention operands T.  N = (S/16)^2 tokens per
+image attend globally (csrc/fw_gattn.hip): N = 64 at 128x128, N = 256 at 256x256 (BASELINE configs[4]).  The image side follows
+`opt.patch_size` like the Uformer classes (the reference's seam passes only `opt` and so always builds for 128, net/model.py:31).
 
-Not built (raise NotImplementedError instead of diverging silently):
-  * image_size != 128: N = 256 tokens need a multi-tile global-attention kernel; the reference cannot construct it either
-    (pos_embedding and the band masks are sized for 128, SURVEY.md 8a row a20);
-  * `frequency_decompose_type` != 'none' (the learnable band re-weighting `lamb` of encoder_ViT.py:56-68,86-92; the option's default
-    is 'none').
-Dropout (p = 0.1 in train mode, encoder_ViT.py:128-129) is not applied: the goldens neutralise it, and the only end-to-end
-configuration of the reference that uses this encoder runs in eval mode.
+Train mode applies every nn.Dropout of the reference (p = 0.1: embedding, attention map, to_out, FeedForward hidden and output;
+encoder_ViT.py:31,33,67,73,158) as counter-based masks: mask = f(seed, call site, element index), re-derived in the backward
+pass, reproduced bit for bit by the CPU oracle (oracle/dropout_hash.py).  The STREAM of random numbers differs from torch's Philox
+stream -- as it does between torch's own CPU and GPU generators -- the Bernoulli(1 - p) / (1 - p) semantics are the reference's.
+
+`frequency_decompose_type` in {'DC', '<n>_bands'}: the learnable band re-weighting `lamb` of encoder_ViT.py:51-66,85-92 runs inside
+the attention kernel (64x64 2-D DFT on the f32 MFMA).  Like the reference it needs N = dim_head = 64, i.e. 128x128 inputs (its masks
+are dim_head x dim_head, :56,60); at any other size both raise.
 """
+import math
+import zlib
+
 import torch
 import torch.nn as nn
 
@@ -40,30 +44,6 @@ class LayerNormF32Fn(torch.autograd.Function):
         db, rb = Fn._grad_target(ctx.beta)
         dx = ops.layernorm_bwd(dy.contiguous().float(), x, gamma, mean, rstd, dg, db, defer=rg is None and rb is None)
         return dx, rg, rb
-
-
-class AddPosFn(torch.autograd.Function):
-    """x [B*N, C] + pos_embedding[:, :N]  (encoder_ViT.py:187); d(pos) = sum over the batch."""
-
-    @staticmethod
-    def forward(ctx, x, pos, B):
-        x = x.contiguous()
-        n = x.shape[0] // B
-        p = pos[0, :n].contiguous()
-        out = torch.empty_like(x)
-        call('fw_add_bcast', x, p, out, x.numel(), p.numel())
-        ctx.geo = (B, n, pos.shape)
-        return out
-
-    @staticmethod
-    def backward(ctx, dy):
-        B, n, pshape = ctx.geo
-        dy = dy.contiguous()
-        dpos = torch.zeros(pshape, dtype=torch.float32, device=dy.device)
-        acc = torch.zeros(n * dy.shape[1], dtype=torch.float32, device=dy.device)
-        ops.colsum(dy.view(B, n * dy.shape[1]), acc)
-        dpos[0, :n] = acc.view(n, dy.shape[1])
-        return dy, dpos, None
 
 
 class BnPlanesFn(torch.autograd.Function):
@@ -138,20 +118,128 @@ class FeedForward(nn.Module):
         self.net = nn.Sequential(nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout), nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
 
 
+_consts = {}
+
+
+def _spectral_tables(kind, nb, device):
+    """(bandidx u8 [64][64] in un-shifted coordinates, f32 cos | sin panels [2][64][64]) of the 64x64 attention-map decomposition
+    (encoder_ViT.py:53-60: FrequencyDecompose('frequency_decompose', 1/nb, 64, 64) or 'frequency_decompose_dc')."""
+    from . import lfs
+    key = (kind, nb, str(device))
+    if key not in _consts:
+        if kind == 'DC':
+            idx = torch.ones((64, 64), dtype=torch.uint8)
+            idx[0, 0] = 0                                                # band 0 = the mean (DC bin), band 1 = everything else
+        else:
+            masks = lfs.band_masks_shifted('frequency_decompose', 1. / nb, 64, 64)
+            shifted = torch.zeros((64, 64), dtype=torch.uint8)
+            for i, m in enumerate(masks):
+                shifted[m] = i
+            assert bool(torch.stack(masks).sum(0).eq(1).all())
+            idx = torch.fft.ifftshift(shifted, dim=(0, 1)).contiguous()
+        assert bool((idx == idx.t()).all())                              # radial masks: the filter commutes with the transpose
+        ang = 2 * math.pi * torch.outer(torch.arange(64, dtype=torch.float64), torch.arange(64, dtype=torch.float64)) / 64
+        panels = torch.stack([torch.cos(ang), torch.sin(ang)]).float().contiguous()
+        _consts[key] = (idx.to(device), panels.to(device))
+    return _consts[key]
+
+
+class GlobalAttnFn(torch.autograd.Function):
+    """qkv: T [B*N, 3*heads*64] (q | k | v) -> out T [B*N, heads*64]  (encoder_ViT.py:76-96 between to_qkv and to_out)."""
+
+    @staticmethod
+    def forward(ctx, qkv, lamb, meta):
+        B, N, heads, p, site, spec = meta
+        inner = heads * 64
+        out = Fn.act_empty(qkv.shape[0], inner, qkv.dtype, qkv.device)
+        lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+        seed = Fn.dropout_seed(qkv.device) if p > 0 else None
+        bidx, panels = spec if spec is not None else (None, None)
+        nb, lb = (lamb.shape[0], lamb.shape[1]) if lamb is not None else (0, 1)
+        lam = lamb.detach().contiguous() if lamb is not None else None
+        call('fw_gattn_fwd', dt(qkv.dtype), qkv, qkv[:, inner:], qkv[:, 2 * inner:], qkv.stride(0), out, out.stride(0), lse, B, heads, N,
+             64 ** -0.5, seed, site, float(p), lam, nb, lb, bidx, panels)
+        ctx.save_for_backward(qkv, out, lse, lam)
+        ctx.meta = (meta, seed)
+        ctx.lamb_param = lamb
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, lam = ctx.saved_tensors
+        (B, N, heads, p, site, spec), seed = ctx.meta
+        inner = heads * 64
+        dout = Fn.aligned(dout)
+        dqkv = Fn.act_empty(qkv.shape[0], qkv.shape[1], qkv.dtype, qkv.device)
+        bidx, panels = spec if spec is not None else (None, None)
+        dlam = rl = None
+        dvec = None
+        if lam is not None:
+            dlam, rl = Fn._grad_target(ctx.lamb_param)
+        else:
+            dvec = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+        nb, lb = (lam.shape[0], lam.shape[1]) if lam is not None else (0, 1)
+        call('fw_gattn_bwd', dt(qkv.dtype), qkv, qkv[:, inner:], qkv[:, 2 * inner:], qkv.stride(0), out, out.stride(0), dout, dout.stride(0),
+             lse, dvec, dqkv, dqkv[:, inner:], dqkv[:, 2 * inner:], dqkv.stride(0), B, heads, N, 64 ** -0.5, seed, site, float(p),
+             lam, dlam, nb, lb, bidx, panels)
+        return dqkv, rl, None
+
+
+class EmbDropFn(torch.autograd.Function):
+    """dropout(x + pos_embedding[:, :N])  (encoder_ViT.py:187-189); x f32 [B*N, C]."""
+
+    @staticmethod
+    def forward(ctx, x, pos, B, site, p):
+        x = x.contiguous()
+        n = x.shape[0] // B
+        pe = pos[0, :n].contiguous()
+        out = torch.empty_like(x)
+        seed = Fn.dropout_seed(x.device) if p > 0 else None
+        call('fw_dropout', 4, 0, x, pe, None, out, x.numel(), pe.numel(), seed, site, float(p))
+        ctx.geo = (B, n, pos.shape, site, p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, n, pshape, site, p, seed = ctx.geo
+        dy = dy.contiguous()
+        if p > 0:
+            dx = torch.empty_like(dy)
+            call('fw_dropout', 0, 0, dy, None, None, dx, dy.numel(), 1, seed, site, float(p))
+        else:
+            dx = dy
+        dpos = torch.zeros(pshape, dtype=torch.float32, device=dy.device)
+        acc = torch.zeros(n * dy.shape[1], dtype=torch.float32, device=dy.device)
+        ops.colsum(dx.view(B, n * dy.shape[1]), acc)
+        dpos[0, :n] = acc.view(n, dy.shape[1])
+        return dx, dpos, None, None, None
+
+
 class Attention(nn.Module):
+    """encoder_ViT.py:38-98."""
+
     def __init__(self, dim, heads=8, dim_head=64, dropout=0., decompose_type='none', wised_batch=None):
         super().__init__()
-        if decompose_type != 'none':
-            raise NotImplementedError("ViT band re-weighting (frequency_decompose_type != 'none', encoder_ViT.py:56-68) is not built")
         if dim_head != 64:
-            raise NotImplementedError(f'the global-attention path is instantiated for head_dim 64, not {dim_head}')
+            raise NotImplementedError(f'the global-attention kernel is instantiated for head_dim 64, not {dim_head}')
         inner = dim_head * heads
         self.heads, self.dim_head = heads, dim_head
         self.scale = dim_head ** -0.5
         self.num_bands = None
+        self._kind = None
+        if decompose_type != 'none':                                     # :51-66
+            if decompose_type.split('_')[-1] == 'bands':
+                self.num_bands = int(decompose_type.split('_')[0])
+                self._kind = 'bands'
+            elif decompose_type == 'DC':
+                self.num_bands = 2
+                self._kind = 'DC'
+            if self.num_bands is not None and not 1 <= self.num_bands <= 16:
+                raise NotImplementedError('band re-weighting: 1..16 bands')
+            self.lamb = nn.Parameter(torch.zeros(self.num_bands, 1 if wised_batch is None else wised_batch, heads))
+        self.dropout = nn.Dropout(dropout)
         self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout))
-        self.register_buffer('_zero_table', torch.zeros(1, 225, heads), persistent=False)
 
 
 class Transformer(nn.Module):
@@ -161,36 +249,58 @@ class Transformer(nn.Module):
             PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout, decompose_type=decompose_type, wised_batch=wised_batch)),
             PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout))]) for _ in range(depth)])
 
-    def run(self, x, B):
-        """x: f32 [B*N, dim] -> same (encoder_ViT.py:112-116: x = attn(x) + x; x = ff(x) + x, both pre-norm)."""
+    def run(self, x, B, site_base=0, training=False):
+        """x: f32 [B*N, dim] -> same (encoder_ViT.py:112-116: x = attn(x) + x; x = ff(x) + x, both pre-norm).
+        Dropout call sites of layer i: site_base + 4 i + {0: attention map, 1: to_out, 2: FeedForward hidden, 3: FeedForward output}."""
         N = x.shape[0] // B
-        side = int(round(N ** 0.5))
-        for attn, ff in self.layers:
+        for li, (attn, ff) in enumerate(self.layers):
             a = attn.fn
+            pa = float(a.dropout.p) if training else 0.0
+            po = float(a.to_out[1].p) if training else 0.0
+            ph = float(ff.fn.net[2].p) if training else 0.0
+            pf = float(ff.fn.net[4].p) if training else 0.0
+            site = site_base + 4 * li
             x, xn = Fn.LnResFn.apply(x, attn.norm.weight, attn.norm.bias)
             qkv = Fn.linear(xn, a.to_qkv.weight)                                              # [B*N, 3 * inner] = q | k | v, head h at column h*64
-            C = a.heads * a.dim_head
-            geo = (C, B, side, side, a.heads, 1, 0, 0, 0)                                     # one 8x8 "window" per image
-            o = Fn.WindowAttnFn.apply(qkv, a._zero_table, None, geo, None, None)
-            x = Fn.linear(o, a.to_out[0].weight, a.to_out[0].bias, residual=x)
+            lamb, spec = None, None
+            if a.num_bands is not None:
+                if N != 64:
+                    raise NotImplementedError('the band re-weighting needs N = dim_head = 64 tokens (128x128 inputs): the reference sizes '
+                                              'its masks dim_head x dim_head (encoder_ViT.py:56,60) and fails otherwise too')
+                if a.lamb.shape[1] not in (1, B):
+                    raise NotImplementedError(f'batch-wise lamb was built for batch {a.lamb.shape[1]}, got {B}')
+                lamb, spec = a.lamb, _spectral_tables(a._kind, a.num_bands, x.device)
+            o = GlobalAttnFn.apply(qkv, lamb, (B, N, a.heads, pa, site, spec))
+            if po > 0:
+                y = Fn.linear(o, a.to_out[0].weight, a.to_out[0].bias, out_f32=True)
+                x = Fn.DropAddFn.apply(y, x, site + 1, po)
+            else:
+                x = Fn.linear(o, a.to_out[0].weight, a.to_out[0].bias, residual=x)
             x, xn = Fn.LnResFn.apply(x, ff.norm.weight, ff.norm.bias)
-            h, g = Fn.linear(xn, ff.fn.net[0].weight, ff.fn.net[0].bias, gelu_out=True)
-            x = Fn.linear(g, ff.fn.net[3].weight, ff.fn.net[3].bias, residual=x, x_pre=h)
+            if ph > 0 or pf > 0:
+                h = Fn.linear(xn, ff.fn.net[0].weight, ff.fn.net[0].bias)
+                g = Fn.GeluDropFn.apply(h.contiguous(), site + 2, ph)
+                y = Fn.linear(g, ff.fn.net[3].weight, ff.fn.net[3].bias, out_f32=True)
+                x = Fn.DropAddFn.apply(y, x, site + 3, pf)
+            else:
+                h, g = Fn.linear(xn, ff.fn.net[0].weight, ff.fn.net[0].bias, gelu_out=True)
+                x = Fn.linear(g, ff.fn.net[3].weight, ff.fn.net[3].bias, residual=x, x_pre=h)
         return x
 
 
 class ViTEncoder(nn.Module):
     """encoder_ViT.py:119-203."""
 
-    def __init__(self, opt, image_size=128, patch_size=16, depth=12, heads=12, mlp_dim=3072, channels=3, dropout=0.1, emb_dropout=0.1):
+    def __init__(self, opt, image_size=None, patch_size=16, depth=12, heads=12, mlp_dim=3072, channels=3, dropout=0.1, emb_dropout=0.1):
         super().__init__()
         out_channels = opt.out_channels
         dim = out_channels * patch_size * patch_size
         self.opt, self.depth = opt, depth
         dim_head = dim // heads
-        if getattr(opt, 'patch_size', 128) not in (None, 128) or image_size != 128:
-            raise NotImplementedError('ViTEncoder is built for 128x128 inputs (64 tokens = one attention tile); the reference cannot '
-                                      'construct another size either (pos_embedding / band masks, SURVEY.md 8a row a20)')
+        if image_size is None:                                           # the seam passes only `opt` (net/model.py:31): follow --patch_size
+            image_size = int(getattr(opt, 'patch_size', None) or 128)
+        if image_size not in (128, 256):
+            raise NotImplementedError(f'ViTEncoder: image_size {image_size}: the global-attention kernel holds N = (S/16)^2 in {{64, 256}} keys per head')
         self.image_height = self.image_width = image_size
         self.patch = patch_size
         num_patches = (image_size // patch_size) ** 2
@@ -204,6 +314,11 @@ class ViTEncoder(nn.Module):
         self.norm = nn.Sequential(nn.BatchNorm2d(opt.encoder_dim), nn.LeakyReLU(0.1, True))
         self.avg = nn.AdaptiveAvgPool2d(1)
         self.mlp = nn.Sequential(nn.Linear(opt.encoder_dim, opt.encoder_dim), nn.LeakyReLU(0.1, True), nn.Linear(opt.encoder_dim, opt.encoder_dim))
+        self.set_prefix('')
+
+    def set_prefix(self, prefix):
+        """MoCo names its two copies (E.E.encoder_q. / E.E.encoder_k.): their Dropout call sites must draw different masks."""
+        self._site_base = ((zlib.crc32(prefix.encode()) & 0xFFFF) << 8) if prefix else 0
 
     def forward(self, x, want_heads=True):
         B, C, H, W = x.shape
@@ -217,8 +332,8 @@ class ViTEncoder(nn.Module):
         t = Fn.LayerNormFn.apply(t, e[1].weight, e[1].bias)
         t = Fn.linear(t, e[2].weight, e[2].bias, out_f32=True)
         t = LayerNormF32Fn.apply(t, e[3].weight, e[3].bias)
-        t = AddPosFn.apply(t, self.pos_embedding, B)
-        t = self.transformer.run(t, B)
+        t = EmbDropFn.apply(t, self.pos_embedding, B, self._site_base + 0xFF, float(self.dropout.p) if self.training else 0.0)
+        t = self.transformer.run(t, B, self._site_base, self.training)
         t = Fn.LayerNormFn.apply(t, self.mlp_head[0].weight, self.mlp_head[0].bias)
         fmap = Fn.linear(t, self.mlp_head[1].weight, self.mlp_head[1].bias)                 # T [B*N, 256 * encoder_dim] = planes [B][ED][H*W]
         bn = self.norm[0]

@@ -242,6 +242,30 @@ int fw_small_linear_fwd(const float* x, const float* w, const float* b, float* y
 int fw_small_linear_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db, int M, int N,
                         int K, float slope, void* stream);
 
+/* ---- ViT global attention (net/encoder_ViT.py:76-98 `Attention.forward`; BASELINE configs[4]: N = 256 tokens at 256x256) -----
+ * q | k | v: T [B*N][ld], head h at column h * 64 (head_dim 64); N in {64, 256}.  out: T [B*N][heads*64]; lse: f32 [B][heads][N].
+ * attn = softmax(q k^T scale) [+ sum_i lamb[i] band_i(attn)] -> dropout(p) -> attn v, one workgroup per (image, head, 64 queries),
+ * the 64 x N score block in registers.  Dropout (encoder_ViT.py:67,94): counter-based mask of (seed[0], site, flat index of the
+ * [B][heads][N][N] map), re-derived by the backward pass; drop_p = 0 or eval: off.  lamb (optional, N = 64 only -- the reference's
+ * masks are dim_head x dim_head, encoder_ViT.py:56,60): f32 [nb][lamb_batch (1 | B)][heads] of encoder_ViT.py:62-66,85-92, evaluated
+ * as a 64x64 2-D DFT on the f32 MFMA; bandidx: u8 [64][64] band of every un-shifted spectrum bin; panels: f32 cos[64][64], sin[64][64]. */
+int fw_gattn_fwd(int dtype, const void* q, const void* k, const void* v, long ld, void* out, long ldo, float* lse, int B, int heads, int N,
+                 float scale, const void* seed, int site, float drop_p, const float* lamb, int nb, int lamb_batch, const void* bandidx,
+                 const float* panels, void* stream);
+/* dq, dk, dv: T, same layout as q / k / v (row stride ldd); dvec: f32 [B][heads][N] scratch (rowsum(dO . O), unused with lamb);
+ * dlamb: accumulated (atomics), same layout as lamb. */
+int fw_gattn_bwd(int dtype, const void* q, const void* k, const void* v, long ld, const void* o, long ldo, const void* dout, long lddo,
+                 const float* lse, float* dvec, void* dq, void* dk, void* dv, long ldd, int B, int heads, int N, float scale,
+                 const void* seed, int site, float drop_p, const float* lamb, float* dlamb, int nb, int lamb_batch, const void* bandidx,
+                 const float* panels, void* stream);
+/* nn.Dropout call sites of the ViT (encoder_ViT.py:31,33,73,158,189) with the same counter-based masks.  mode 0: y = drop(x) (f32);
+ * 1: y = res + drop(x) (f32); 2: y = drop(gelu(x)) (T); 3: y = drop(x) * gelu'(aux) (T, backward of 2); 4: y = drop(x + aux[i % period])
+ * (f32: pos_embedding add + emb dropout, encoder_ViT.py:187-189).  n = elements of the contiguous tensor; p = 0: identity masks. */
+int fw_dropout(int mode, int dtype, const void* x, const void* aux, const float* res, void* y, long n, long period, const void* seed, int site,
+               float p, void* stream);
+/* seed[0] += 1 (u32 in device memory): once per training step, inside the captured graph */
+int fw_rng_tick(void* seed, void* stream);
+
 /* ---- fused LeFF forward (net/utils/leff.py:92-117) for the high-resolution stages, bf16 operands ----------------------------
  * y = res + rowscale * linear2(GELU(dwconv3x3(GELU(linear1(xn))))) in one kernel per 8 x 16 pixel patch: the hidden tensor is
  * produced and consumed on chip (7 chunks of 4C/7 channels); h1, g1, h2, g2 (bf16 [T][4C]) are WRITTEN for the unfused backward

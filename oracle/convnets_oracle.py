@@ -156,36 +156,67 @@ def dgrn(st, p, x, inter, n_groups=5, n_blocks=5, dcn=dcn_layer):
 # --------------------------------------------------------------------------------------
 # ViT encoder  (net/encoder_ViT.py)
 # --------------------------------------------------------------------------------------
-def vit_attention(st, p, x, heads):
-    """Attention.forward, encoder_ViT.py:76-98 without the band re-weighting (frequency_decompose_type 'none', option.py default)."""
+def _drop(t, drop, layer, which):
+    """nn.Dropout with the product's counter-based mask (oracle/dropout_hash.py); drop = (seed, site base, p) or None."""
+    if drop is None or drop[2] <= 0:
+        return t
+    import dropout_hash as DH
+    seed, base, p = drop
+    m = torch.from_numpy(DH.keep_mask(seed, DH.vit_site(base, layer, which), tuple(t.shape), p))
+    return t * m.to(t.dtype) / (1.0 - p)
+
+
+def attn_band_masks(decompose_type, n=64):
+    """Band masks of the ViT's attention-map decomposition in UN-shifted spectrum coordinates, [nb, n, n] bool
+    (encoder_ViT.py:51-60: FrequencyDecompose('frequency_decompose', 1/nb, dim_head, dim_head) | 'frequency_decompose_dc')."""
+    import airnet_oracle as A
+    if decompose_type == 'DC':
+        m = torch.zeros(2, n, n, dtype=torch.bool)
+        m[0, 0, 0] = True
+        m[1] = ~m[0]
+        return m
+    nb = int(decompose_type.split('_')[0])
+    shifted = torch.stack(A.band_masks('frequency_decompose', 1. / nb, n, n))
+    return torch.fft.ifftshift(shifted, dim=(-2, -1))
+
+
+def vit_attention(st, p, x, heads, decompose_type='none', drop=None, layer=0):
+    """Attention.forward, encoder_ViT.py:76-98: softmax(q k^T scale) [+ sum_i lamb_i band_i(attn)] -> dropout -> attn v -> to_out -> dropout."""
     B, N, C = x.shape
     qkv = F.linear(x, st[p + 'to_qkv.weight']).chunk(3, dim=-1)
     q, k, v = (t.reshape(B, N, heads, -1).transpose(1, 2) for t in qkv)
     D = q.shape[-1]
     attn = ((q @ k.transpose(-1, -2)) * D ** -0.5).softmax(-1)
+    if decompose_type != 'none':
+        masks = attn_band_masks(decompose_type, D)                               # sized dim_head (:56,60): needs N == D
+        spec = torch.fft.fft2(attn)
+        bands = torch.stack([torch.fft.ifft2(spec * m).real for m in masks.to(attn.dtype)], 0)   # [nb, B, heads, N, N]
+        attn = attn + (bands * st[p + 'lamb'][:, :, :, None, None]).sum(0)
+    attn = _drop(attn, drop, layer, 'attn')
     out = (attn @ v).transpose(1, 2).reshape(B, N, heads * D)
-    return F.linear(out, st[p + 'to_out.0.weight'], st[p + 'to_out.0.bias'])
+    return _drop(F.linear(out, st[p + 'to_out.0.weight'], st[p + 'to_out.0.bias']), drop, layer, 'out')
 
 
-def vit_encoder(st, p, opt, x, training, bn_update=None, depth=12, heads=12, patch=16):
-    """ViTEncoder.forward, encoder_ViT.py:181-203, dropout = identity (eval, or p = 0 in the golden train runs).
-    -> (fea [B, encoder_dim], [out], inter [B, encoder_dim, H, W])."""
+def vit_encoder(st, p, opt, x, training, bn_update=None, depth=12, heads=12, patch=16, drop=None):
+    """ViTEncoder.forward, encoder_ViT.py:181-203.  drop = (seed, site base, p): the train-mode Dropouts with the product's masks;
+    None: identity (eval, or the p = 0 golden runs).  -> (fea [B, encoder_dim], [out], inter [B, encoder_dim, H, W])."""
     B, C, H, W = x.shape
     hh, ww = H // patch, W // patch
+    dtype = getattr(opt, 'frequency_decompose_type', 'none') or 'none'
     t = x.reshape(B, C, hh, patch, ww, patch).permute(0, 2, 4, 3, 5, 1).reshape(B, hh * ww, patch * patch * C)   # b (h w) (p1 p2 c)
     e = p + 'to_patch_embedding.'
     t = F.layer_norm(t, (t.shape[-1],), st[e + '1.weight'], st[e + '1.bias'])
     t = F.linear(t, st[e + '2.weight'], st[e + '2.bias'])
     t = F.layer_norm(t, (t.shape[-1],), st[e + '3.weight'], st[e + '3.bias'])
     dim = t.shape[-1]
-    t = t + st[p + 'pos_embedding'][:, :t.shape[1]]
+    t = _drop(t + st[p + 'pos_embedding'][:, :t.shape[1]], drop, 0, 'emb')
     for i in range(depth):
         a = p + f'transformer.layers.{i}.0.'
-        t = vit_attention(st, a + 'fn.', F.layer_norm(t, (dim,), st[a + 'norm.weight'], st[a + 'norm.bias']), heads) + t
+        t = vit_attention(st, a + 'fn.', F.layer_norm(t, (dim,), st[a + 'norm.weight'], st[a + 'norm.bias']), heads, dtype, drop, i) + t
         f = p + f'transformer.layers.{i}.1.'
         h = F.layer_norm(t, (dim,), st[f + 'norm.weight'], st[f + 'norm.bias'])
-        h = F.gelu(F.linear(h, st[f + 'fn.net.0.weight'], st[f + 'fn.net.0.bias']))
-        t = F.linear(h, st[f + 'fn.net.3.weight'], st[f + 'fn.net.3.bias']) + t
+        h = _drop(F.gelu(F.linear(h, st[f + 'fn.net.0.weight'], st[f + 'fn.net.0.bias'])), drop, i, 'hidden')
+        t = _drop(F.linear(h, st[f + 'fn.net.3.weight'], st[f + 'fn.net.3.bias']), drop, i, 'ff') + t
     t = F.layer_norm(t, (dim,), st[p + 'mlp_head.0.weight'], st[p + 'mlp_head.0.bias'])
     t = F.linear(t, st[p + 'mlp_head.1.weight'], st[p + 'mlp_head.1.bias'])
     inter = t.reshape(-1, opt.encoder_dim, H, W)
@@ -199,12 +230,18 @@ def vit_encoder(st, p, opt, x, training, bn_update=None, depth=12, heads=12, pat
 # --------------------------------------------------------------------------------------
 # AirNet with these plug-ins (net/model.py:59-71, net/utils/moco.py:115-166)
 # --------------------------------------------------------------------------------------
-def airnet_forward(st, opt, x_query, x_key, training, decoder, update_state=True):
+def airnet_forward(st, opt, x_query, x_key, training, decoder, update_state=True, drop=None):
     """AirNet.forward for the ResNet / ViT encoders.  The reference's MoCo indexes `range(opt.L)` heads on their 1-element output
     list and fails (moco.py:127-128); as the build does, the contrastive loss runs over len(q) = 1 head against
     queue[0].  decoder(st, x_query, inter) -> restored.  Train: (restored, [logits], [labels]); eval: restored."""
     import airnet_oracle as A
-    enc = resnet_encoder if opt.encoder_type == 'ResNet' else (lambda s, p, x, t, b=None: vit_encoder(s, p, opt, x, t, b))
+    def vit(s, p, x, t, b=None):
+        d = None
+        if drop is not None and t:                       # drop = (seed, p): train-mode Dropout masks of the product, per encoder copy
+            import dropout_hash as DH
+            d = (drop[0], DH.site_base(p), drop[1])
+        return vit_encoder(s, p, opt, x, t, b, drop=d)
+    enc = resnet_encoder if opt.encoder_type == 'ResNet' else vit
     if not training:
         _, _, inter = enc(st, 'E.E.encoder_q.', x_query, False)
         return decoder(st, x_query, inter)

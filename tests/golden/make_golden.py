@@ -6,7 +6,7 @@ Imports the unmodified reference through ``oracle/refshim.py`` (timm stand-in, n
 inputs with DropPath neutralised and stores inputs + outputs as small ``.npz`` files
 (``numpy.load`` with ``allow_pickle=False`` reads them) plus the state-dict schema as JSON.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [unit] [model] [moco] [model256] [debug] [convnets] [vit]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [unit] [model] [moco] [model256] [debug] [convnets] [vit] [vit256] [vitlamb] [kdiff]
 
 A fixture is data (inputs / expected outputs); no reference source text is stored.
 """
@@ -236,6 +236,35 @@ def gen_model():
         json.dump(schemas, f)
 
 
+def gen_kdiff():
+    """A training step whose contrastive loss is O(1): with name-seeded weights the encoder's embedding is all but
+    input-independent, so with encoder_k == encoder_q the InfoNCE term is 6e-6 whatever the key image is and the encoder's gradients are
+    ~1e-7.  Here the key encoder keeps its OWN name-seeded weights (no q -> k copy): l_pos is the cosine of two unrelated embeddings,
+    the contrastive term is ~1.3 and the query encoder's backward is pinned at real magnitudes.  all_3_bands / L = 3 / freq, batch 2."""
+    set_opt(batch_size=2, degradation_embedding_method=['all_3_bands'], L=3, encoder_msa_type='freq')
+    net = seed_module(AirNet(opt), '')
+    clean, q, k = synth_batch(2, 128, 'model.')
+    net.train()
+    restored, logits, labels = net(x_query=q, x_key=k)
+    CE = torch.nn.CrossEntropyLoss()
+    contrast = sum(CE(logits[i], labels[i]) for i in range(opt.L)) / opt.L
+    l1 = torch.nn.L1Loss()(restored, clean)
+    loss = l1 + opt.contrast_loss_weight * contrast
+    g = grads_of(net, loss)
+    names = sorted(g.keys())
+    arrs = {'restored_train': restored, 'logits': torch.stack(logits, 0), 'loss': loss, 'l1': l1, 'contrast': contrast,
+            'grad_names': np.array(names), 'grad_norms': np.array([g[n].norm().item() for n in names]),
+            'queue_after': net.E.E.queue, 'queue_ptr_after': net.E.E.queue_ptr}
+    for n in names:
+        if n.startswith('E.E.encoder_q.') and g[n].numel() <= 4096 and ('blocks.0.' in n or 'blocks.1.' in n or 'mlp.' in n or 'norm' in n):
+            arrs['g.' + n] = g[n]
+    for n in ('E.E.encoder_q.uformer.input_proj.proj.0.weight', 'E.E.encoder_q.uformer.dowsample_0.conv.0.weight',
+              'E.E.encoder_q.uformer.encoderlayer_1.blocks.1.attn_inter.qkv.to_kv.weight', 'R.R.output_proj.proj.0.weight'):
+        arrs['g.' + n] = g[n]
+    save('model_all3_kdiff', **arrs)
+    print('kdiff: contrast %.4f' % float(contrast))
+
+
 def gen_model256():
     """Resolution-generic row: the reference's own classes built with img_size=256 -- the seam `cls(opt)` always
     takes the 128 default (net/model.py:17,31), so the two registered names are rebound to 256-pixel constructors for this run.
@@ -401,6 +430,118 @@ def gen_vit():
         set_opt(encoder_type='Uformer', decoder_type='Uformer', encoder_dim=256, degradation_embedding_method=['all_3_bands'])
 
 
+DROP_SEED = 20240917
+
+
+def patch_dropout(seed):
+    """torch.nn.Dropout.forward of the IMPORTED reference draws the product's counter-based masks (oracle/dropout_hash.py) at the
+    call sites numbered by `assign_vit_sites`: train-mode goldens with Dropout ON become deterministic statements.  torch's own
+    Philox stream cannot be matched by a HIP kernel (it differs between torch's CPU and GPU generators too); the Bernoulli(1-p)/(1-p)
+    arithmetic is untouched."""
+    import dropout_hash as DH
+
+    def forward(self, x):
+        site = getattr(self, '_site', None)
+        if not self.training or self.p == 0 or site is None:
+            return x
+        m = torch.from_numpy(DH.keep_mask(seed, site, tuple(x.shape), self.p)).to(x.dtype)
+        return x * m / (1.0 - self.p)
+    torch.nn.Dropout.forward = forward
+
+
+def assign_vit_sites(enc, prefix):
+    import dropout_hash as DH
+    base = DH.site_base(prefix)
+    enc.dropout._site = DH.vit_site(base, 0, 'emb')
+    for i, (attn, ff) in enumerate(enc.transformer.layers):
+        attn.fn.dropout._site = DH.vit_site(base, i, 'attn')
+        attn.fn.to_out[1]._site = DH.vit_site(base, i, 'out')
+        ff.fn.net[2]._site = DH.vit_site(base, i, 'hidden')
+        ff.fn.net[4]._site = DH.vit_site(base, i, 'ff')
+
+
+def vit_encoder_arrays(enc, x, tag, sub):
+    """eval outputs + train-mode (Dropout ON, hashed masks) outputs and gradients of a reference ViTEncoder; `inter` maps are kept
+    at every sub-th pixel (fixture size)."""
+    enc.eval()
+    with torch.no_grad():
+        fea, out, inter = enc(x)
+    a = {'fea_eval': fea, 'out_eval': out[0], 'inter_eval': inter[:, :, ::sub, ::sub]}         # x is seeded: rnd(tag + 'x')
+    enc.train()
+    fea, out, inter = enc(x)
+    w1, w2 = rnd(tag + 'dout', out[0].shape), rnd(tag + 'dinter', inter.shape)
+    g = grads_of(enc, (out[0] * w1).sum() + (inter * w2).sum())
+    names = sorted(g.keys())
+    a.update({'fea_train': fea, 'out_train': out[0], 'inter_train': inter[:, :, ::sub, ::sub],
+              'grad_names': np.array(names), 'grad_norms': np.array([g[n].norm().item() for n in names])})
+    for n in names:
+        if g[n].numel() <= 4096:
+            a['g.' + n] = g[n]
+    a.update({'s.' + k: v for k, v in enc.state_dict().items() if 'running' in k})
+    return a
+
+
+def gen_vit256():
+    """BASELINE configs[4]: the reference's ViTEncoder constructed with image_size=256 (N = 256 tokens, pos_embedding [1, 256, 768]):
+    eval, and TRAIN mode with every Dropout at its p = 0.1 (hashed masks, see patch_dropout); plus ViT(256) + plain Uformer decoder
+    built with img_size=256, eval forward (the seam's names are rebound to the 256-pixel constructors, as gen_model256 does)."""
+    from net import encoder_ViT as RV
+    import net.model as RM
+    set_opt(encoder_type='ViT', decoder_type='Uformer', encoder_dim=3, batch_size=2, degradation_embedding_method=['None'],
+            frequency_decompose_type='none', out_channels=3, batch_wise_decompose=False)
+    keep_fwd = torch.nn.Dropout.forward
+    try:
+        patch_dropout(DROP_SEED)
+        pre = 'E.E.encoder_q.'
+        enc = seed_module(RV.ViTEncoder(opt, image_size=256), pre)
+        assign_vit_sites(enc, pre)
+        x = rnd('vit256.x', (2, 3, 256, 256), 0.5)
+        save('model_vit256_encoder', drop_seed=np.int64(DROP_SEED), **vit_encoder_arrays(enc, x, 'vit256.', 4))
+        keep = RM.ViTEncoder, RM.UformerDecoder
+        RM.ViTEncoder = lambda o: RV.ViTEncoder(o, image_size=256)
+        RM.UformerDecoder = lambda o: RD.UformerDecoder(o, img_size=256)
+        try:
+            set_opt(batch_size=1)
+            net = seed_module(AirNet(opt), '')
+        finally:
+            RM.ViTEncoder, RM.UformerDecoder = keep
+        for pq, pk in zip(net.E.E.encoder_q.parameters(), net.E.E.encoder_k.parameters()):
+            pk.data.copy_(pq.data)
+        sch = json.load(open(os.path.join(HERE, 'schema.json')))
+        sch['vit256_uformer'] = schema_of(net)
+        json.dump(sch, open(os.path.join(HERE, 'schema.json'), 'w'))
+        clean, q, k = synth_batch(1, 256, 'model256.')
+        net.eval()
+        with torch.no_grad():
+            restored = net(x_query=q, x_key=q)
+        save('model_vit256_uformer', restored_eval=restored[:, :, ::2, ::2], psnr_eval=O.psnr(restored, clean))
+    finally:
+        torch.nn.Dropout.forward = keep_fwd
+        set_opt(encoder_type='Uformer', decoder_type='Uformer', encoder_dim=256, degradation_embedding_method=['all_3_bands'], batch_size=2)
+
+
+def gen_vit_lamb():
+    """The learnable band re-weighting of the ViT attention maps (encoder_ViT.py:51-66,85-92) at 128x128 (N = dim_head = 64, where the
+    reference runs it): frequency_decompose_type '3_bands', 'DC' and batch-wise 'DC'; eval + train (Dropout ON, hashed masks);
+    `lamb` is seeded non-zero like every other parameter (the reference initialises it to zeros)."""
+    from net import encoder_ViT as RV
+    keep_fwd = torch.nn.Dropout.forward
+    try:
+        patch_dropout(DROP_SEED)
+        for tag, ftype, bw in (('3bands', '3_bands', False), ('DC', 'DC', False), ('DCbw', 'DC', True)):
+            set_opt(encoder_type='ViT', decoder_type='Uformer', encoder_dim=3, batch_size=2, degradation_embedding_method=['None'],
+                    frequency_decompose_type=ftype, out_channels=3, batch_wise_decompose=bw)
+            pre = 'E.E.encoder_q.'
+            enc = seed_module(RV.ViTEncoder(opt), pre)
+            assign_vit_sites(enc, pre)
+            x = rnd('vitlamb.x', (2, 3, 128, 128), 0.5)
+            save(f'model_vit_lamb_{tag}', drop_seed=np.int64(DROP_SEED), **vit_encoder_arrays(enc, x, 'vitlamb.', 4))
+    finally:
+        torch.nn.Dropout.forward = keep_fwd
+        set_opt(encoder_type='Uformer', decoder_type='Uformer', encoder_dim=256, degradation_embedding_method=['all_3_bands'], batch_size=2,
+                frequency_decompose_type='none', batch_wise_decompose=False)
+
+
 def gen_moco():
     """Three consecutive train-mode steps of the encoder side only (net.E), SGD lr 0.05 on the
     query encoder in between, so that EMA, queue rotation and pointer wrap are all exercised."""
@@ -450,3 +591,9 @@ if __name__ == '__main__':
             gen_convnets()
         if 'vit' in what:
             gen_vit()
+        if 'vit256' in what:
+            gen_vit256()
+        if 'kdiff' in what:
+            gen_kdiff()
+        if 'vitlamb' in what:
+            gen_vit_lamb()

@@ -57,3 +57,13 @@ def close(a, b, tol, what=''):
     err = (a - b).abs().max().item() / scale
     assert err < tol, f'{what}: rel-to-max err {err:.3e} >= {tol:.1e} (scale {scale:.3e})'
     return err
+
+
+def kdiff_state(variant='all3'):
+    """Seeded state whose key encoder keeps its OWN name-seeded weights (golden model_all3_kdiff: the contrastive loss is O(1))."""
+    sch = schema(variant)
+    st = O.fill_state_seeded(sch)
+    for name, shape, _ in sch:
+        if name.startswith('E.E.encoder_k.') and O.is_parameter_key(name):
+            st[name] = O.seeded_tensor(name, tuple(shape))
+    return st

@@ -243,6 +243,9 @@ def test_vit_encoder_vs_reference(dt):
     close(out[0], g['out_eval'], t1, 'out (eval)')
     close(inter, g['inter_eval'], t1, 'inter (eval)')
     enc.train()
+    for m in enc.modules():                                   # this golden's train run has every Dropout at p = 0 (make_golden.py gen_vit);
+        if isinstance(m, torch.nn.Dropout):                   # Dropout ON is pinned by tests/test_vit256_gpu.py
+            m.p = 0.0
     fea, out, inter = enc(x)
     close(out[0], g['out_train'], t1, 'out (train)')
     close(inter, g['inter_train'], t1, 'inter (train)')

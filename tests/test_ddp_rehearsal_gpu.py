@@ -31,3 +31,21 @@ def test_two_ranks_three_graph_step_on_one_gpu():
     assert 'capture failed' not in r.stderr and 'all-reduce will follow the backward pass' not in r.stderr
     assert all(math.isfinite(v) for v in d['loss'].values()) and 0.0 < d['loss']['l1'] < 1.0
     assert d['value'] > 0
+
+
+def test_plain_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torchrun around it (the way the driver invokes `--gpus 1`): bench.py must start the two
+    ranks itself, before any HIP call, and rank 0 must report n_gpus = 2."""
+    env = dict(os.environ, FW_DIST_BACKEND='gloo', FW_DIST_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
+           '--no-cpu-baseline', '--no-profile']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, 'rank 0 prints exactly one JSON line'
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 4
+    assert d['config']['hip_graph'] is True
+    assert all(math.isfinite(v) for v in d['loss'].values())

@@ -172,6 +172,44 @@ def test_eval_after_graph_replayed_steps_sees_current_weights():
     assert torch.equal(a, b)
 
 
+def test_graph_steps_survive_eval_and_empty_cache():
+    """ADVICE r2 (use-after-free of weight shadows behind captured graphs): graph steps, an eval forward (which re-derives the
+    re-laid-out weight copies -- it must do so INTO the buffers the graph captured), torch.cuda.empty_cache(), a foreign
+    allocation, then more graph steps: losses and parameters equal an eager engine fed the same sequence."""
+    from fwair import engine as E
+    from fwair import functional as Fn
+    clean, q, k = (t.to(DEV) for t in synth_batch(2, 128, 'uaf.'))
+
+    def run(graph):
+        net, opt = build('all3', 'bf16')
+        net.train()
+        eng = E.TrainEngine(net, lr=1e-3, contrast_loss_weight=0.6, use_graph=graph)
+        losses = []
+        for _ in range(2):
+            losses.append(eng.step(q, k, clean).clone())
+        net.eval()
+        with torch.no_grad():
+            ev = net(x_query=q, x_key=q).clone()
+        net.train()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        junk = [torch.full((1 << 22,), float('nan'), device=DEV) for _ in range(16)]      # reuse whatever was freed
+        for _ in range(2):
+            losses.append(eng.step(q, k, clean).clone())
+        torch.cuda.synchronize()
+        del junk
+        flat = eng.flat_p.clone()
+        Fn.config.direct_grads = False
+        return torch.stack(losses), ev, flat
+
+    la, eva, pa = run(True)
+    lb, evb, pb = run(False)
+    assert torch.isfinite(la).all() and torch.isfinite(pa).all()
+    close(la, lb, 2e-3, 'losses graph vs eager across an eval + empty_cache')
+    close(eva, evb, 2e-3, 'eval output between the steps')
+    close(pa, pb, 2e-3, 'parameters after the fourth step')
+
+
 def test_256_resolution_fp32_and_bf16():
     """Resolution-generic construction: `opt.patch_size=256` through the unchanged seam, against the golden made by
     the reference's classes with img_size=256 (16x16 bottleneck with shifted odd blocks, 256-token LFS heads, 256-point band DFT)."""

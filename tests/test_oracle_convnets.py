@@ -114,6 +114,63 @@ def test_vit_encoder():
     check_grads(st, g, 2e-4)
 
 
+def _vit_case(gname, variant, size, tag, lamb_shape=None, **opt_kw):
+    """Oracle ViT encoder against a reference golden: eval, and train mode with Dropout ON (the hashed masks both sides draw)."""
+    import dropout_hash as DH
+    from helpers import rnd
+    g = load(gname)
+    pre = 'E.E.encoder_q.'
+    st = seeded(pre, variant)
+    if lamb_shape is not None:
+        for i in range(12):
+            key = f'transformer.layers.{i}.0.fn.lamb'
+            st[key] = O.seeded_tensor(pre + key, lamb_shape)
+    opt = make_opt('all3', encoder_type='ViT', encoder_dim=3, **opt_kw)
+    x = rnd(tag + 'x', (2, 3, size, size), 0.5)
+    with torch.no_grad():
+        fea, out, inter = C.vit_encoder(st, '', opt, x, False)
+    close(fea, g['fea_eval'], 2e-5, 'fea (eval)')
+    close(out[0], g['out_eval'], 2e-5, 'out (eval)')
+    close(inter[:, :, ::4, ::4], g['inter_eval'], 2e-5, 'inter (eval)')
+    names = [str(n) for n in g['grad_names']]
+    for n in names:
+        st[n] = st[n].clone().requires_grad_(True)
+    upd = {}
+    fea, out, inter = C.vit_encoder(st, '', opt, x, True, upd, drop=(int(g['drop_seed']), DH.site_base(pre), 0.1))
+    close(out[0], g['out_train'], 5e-5, 'out (train, Dropout on)')
+    close(inter[:, :, ::4, ::4], g['inter_train'], 5e-5, 'inter (train, Dropout on)')
+    ((out[0] * rnd(tag + 'dout', out[0].shape)).sum() + (inter * rnd(tag + 'dinter', inter.shape)).sum()).backward()
+    norms = torch.tensor([st[n].grad.norm().item() for n in names], dtype=torch.float64)
+    close(norms, g['grad_norms'], 2e-4, 'gradient norms')
+    check_grads(st, g, 2e-4)
+
+
+def test_vit_encoder_256_with_dropout():
+    """BASELINE configs[4]: N = 256 tokens (the reference class constructed with image_size=256)."""
+    _vit_case('model_vit256_encoder', 'vit256_uformer', 256, 'vit256.')
+
+
+@pytest.mark.parametrize('tag,ftype,bw,shape', [('3bands', '3_bands', False, (3, 1, 12)), ('DC', 'DC', False, (2, 1, 12)),
+                                                ('DCbw', 'DC', True, (2, 2, 12))])
+def test_vit_encoder_band_reweighting(tag, ftype, bw, shape):
+    """encoder_ViT.py:51-66,85-92: learnable lamb per (band, [sample,] head) on the 64x64 attention maps."""
+    _vit_case(f'model_vit_lamb_{tag}', 'vit_uformer', 128, 'vitlamb.', lamb_shape=shape, frequency_decompose_type=ftype,
+              batch_wise_decompose=bw)
+
+
+def test_dropout_hash_statistics():
+    """The counter-based masks are Bernoulli(1 - p): rate, independence across sites and seeds, no short-range structure."""
+    import numpy as np
+    import dropout_hash as DH
+    m = DH.keep_mask(1234, 7, (1 << 20,), 0.1)
+    assert abs(m.mean() - 0.9) < 2e-3
+    m2 = DH.keep_mask(1234, 8, (1 << 20,), 0.1)
+    m3 = DH.keep_mask(1235, 7, (1 << 20,), 0.1)
+    for o in (m2, m3, np.roll(m, 1), np.roll(m, 64)):
+        assert abs(np.corrcoef(m, o)[0, 1]) < 5e-3
+    assert DH.keep_mask(1, 2, (8, 8), 0.0).all()
+
+
 # ---- DCNv2: known-answer tests (SURVEY 8c) ------------------------------------------------------------------------------------
 def test_dcn_zero_offsets_is_half_a_convolution():
     """deform_conv.py:52-54 zero-initialises conv_offset_mask: offsets 0, mask = sigmoid(0) = 0.5 => DCN(x) = 0.5 * conv2d(x, W, pad 1)."""

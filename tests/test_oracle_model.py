@@ -46,6 +46,35 @@ def test_train_step(variant):
     close(st['E.E.encoder_k.norm.0.0.running_mean'], g['bn_k0_running_mean'], 1e-4, 'bn running mean (k)')
 
 
+def test_train_step_with_order_one_contrastive_loss():
+    """golden model_all3_kdiff (reference run with an independently seeded key encoder): contrast ~ 1.27, so the InfoNCE path and the
+    query encoder's backward are pinned at real magnitudes, not at the 6e-6 / 1e-7 of the q == k goldens."""
+    from helpers import kdiff_state
+    g = load('model_all3_kdiff')
+    st = kdiff_state()
+    names = [str(n) for n in g['grad_names']]
+    for n in names:
+        st[n] = st[n].clone().requires_grad_(True)
+    opt = make_opt('all3')
+    clean, q, k = synth_batch(2, 128, 'model.')
+    restored, logits, labels = O.airnet_forward(st, opt, q, k, True)
+    loss, l1, contrast = O.training_loss(opt, restored, logits, labels, clean)
+    assert float(g['contrast']) > 1.0
+    close(contrast, g['contrast'], 1e-5, 'contrast')
+    close(torch.stack(logits), g['logits'], 1e-4, 'logits')
+    close(loss, g['loss'], 1e-5, 'loss')
+    loss.backward()
+    norms = torch.tensor([st[n].grad.norm().item() for n in names])
+    close(norms, g['grad_norms'], 1e-3, 'per-parameter grad norms')
+    enc = [i for i, n in enumerate(names) if n.startswith('E.E.encoder_q.')]
+    rel = ((norms[enc] - g['grad_norms'][enc]).abs() / g['grad_norms'][enc].clamp_min(1e-12))
+    assert rel.max() < 2e-2 and rel.median() < 1e-3, f'encoder grad norms: max rel {rel.max():.2e} ({names[enc[int(rel.argmax())]]})'
+    for key, val in g.items():
+        if key.startswith('g.'):
+            close(st[key[2:]].grad, val, 2e-3, key)
+    close(st['E.E.queue'], g['queue_after'], 1e-5, 'queue')
+
+
 def test_256_eval_and_train_step():
     """Resolution-generic construction: the reference classes built with img_size=256 (golden model256_all3) -- the
     bottleneck is 16x16 there, so its odd blocks shift, the LFS heads average 256 tokens and the band split is a 256-point DFT."""

@@ -55,8 +55,8 @@ __global__ void train_batch_kernel(const long long* __restrict__ tab, const int*
             }
         }
         const long o = ((long)b * 3 + c) * S * S + (long)oy * S + ox;
-        (v ? d2 : d1)[o] = d * (1.0f / 255.0f);
-        (v ? c2 : c1)[o] = g * (1.0f / 255.0f);
+        (v ? d2 : d1)[o] = __fdiv_rn(d, 255.0f);                                 // ToTensor divides (correctly rounded), bit-exact with numpy
+        (v ? c2 : c1)[o] = __fdiv_rn(g, 255.0f);
     }
 }
 

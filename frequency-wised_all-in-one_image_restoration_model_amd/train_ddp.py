@@ -83,13 +83,14 @@ def evaluate_tasks(net, epoch, dev, results):
     """train.py:131-139: after every phase-2 epoch, `<E> Epochs Results:` and one `task: PSNR/SSIM` line per test task in results.log.
     The tiles are restored by fwair.evaluate.tiled_restore (test.py:48-71 on the device, averaging the RESTORED tiles).  With
     `--synthetic_steps` the test images are synthetic too (4 images of 1.5 x patch_size per task); otherwise the reference's
-    TestDataset is read.  SSIM needs scikit-image, which this package does not depend on: the field is written as nan."""
+    TestDataset is read.  PSNR and SSIM (utils/val_utils.py:50-66) are computed on the device (fwair.evaluate: fw_ssim7 restates
+    skimage's structural_similarity defaults)."""
     from fwair import augment as A
-    from fwair.evaluate import psnr, tiled_restore
+    from fwair.evaluate import psnr, ssim, tiled_restore
     results.write('%s Epochs Results:\n' % str(epoch + 1))
     net.eval()
     for task in opt.test_de_type:
-        vals = []
+        vals, svals = [], []
         if _ARGS.synthetic_steps > 0:
             S = opt.patch_size * 3 // 2
             clean, _, _ = synth_batch(4, S, 0, 4321, dev)
@@ -100,16 +101,29 @@ def evaluate_tasks(net, epoch, dev, results):
                     deg = A.degrade(cu8[i], task, g).float().div_(255.0)     # 'denoising_bsd68_25' -> sigma 25; deraining; dehazing
                 except ValueError:
                     break                                                    # a task without a synthetic stand-in (deblurring)
-                vals.append(psnr(tiled_restore(net, deg[None], opt.crop_test_imgs_size), clean[i:i + 1]))
+                rest = tiled_restore(net, deg[None], opt.crop_test_imgs_size)
+                vals.append(psnr(rest, clean[i:i + 1])); svals.append(ssim(rest, clean[i:i + 1]))
         else:
             from torch.utils.data import DataLoader
             from utils.dataset_utils import TestDataset
             for (_, inp, cl) in DataLoader(TestDataset(opt, task), batch_size=1, shuffle=False, num_workers=0):
-                vals.append(psnr(tiled_restore(net, inp.to(dev), opt.crop_test_imgs_size), cl.to(dev)))
-        result = 'PSNR/SSIM: %.2f/%.4f' % (sum(vals) / len(vals) if vals else float('nan'), float('nan'))
+                rest = tiled_restore(net, inp.to(dev), opt.crop_test_imgs_size)
+                vals.append(psnr(rest, cl.to(dev))); svals.append(ssim(rest, cl.to(dev)))
+        result = 'PSNR/SSIM: %.2f/%.4f' % (sum(vals) / len(vals) if vals else float('nan'), sum(svals) / len(svals) if svals else float('nan'))
         results.write(task + ': ' + ' ' * (25 - len(task)) + result + '\n')
     results.flush()
     net.train()
+
+
+def _epoch_rendezvous(rank, world, epoch):
+    """End-of-epoch meeting point that a long evaluation on rank 0 cannot time out: a counter in the process group's TCP store (no
+    RCCL collective is pending while rank 0 runs its eval forwards), then one ordinary barrier once everybody has arrived."""
+    store = torch.distributed.distributed_c10d._get_default_store()
+    key = f'fw_epoch_{epoch}'
+    store.add(key, 1)
+    while int(store.add(key, 0)) < world:
+        time.sleep(0.05)
+    torch.distributed.barrier()
 
 
 def main():
@@ -174,7 +188,9 @@ def main():
         if epoch >= opt.epochs_encoder and rank == 0 and not _ARGS.no_eval:     # train.py:131-139 (rank 0 only: an eval forward has no collective)
             evaluate_tasks(net, epoch, dev, results)
         if world > 1:
-            torch.distributed.barrier()
+            # the other ranks wait here while rank 0 evaluates: a host-side (gloo-free) wait with no collective timeout -- rank 0
+            # publishes the epoch through the store, the others poll it
+            _epoch_rendezvous(rank, world, epoch)
         eng.set_lr(lr_for_next_epoch(epoch))
     if log:
         log.close()

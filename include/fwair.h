@@ -266,6 +266,23 @@ int fw_dropout(int mode, int dtype, const void* x, const void* aux, const float*
 /* seed[0] += 1 (u32 in device memory): once per training step, inside the captured graph */
 int fw_rng_tick(void* seed, void* stream);
 
+/* ---- callers either side of the model -----------------------------------------------------------------------
+ * fw_train_batch: one launch = one training batch from uint8 images resident in HBM (utils/dataset_utils.py:122-135,
+ * utils/image_utils.py:133-182): tab: device int64 [B][4] = {clean u8 [3][H][W], degraded u8 or 0, H, W}; rnd: device int32 [B][6] =
+ * non-negative random integers {y1, x1, mode1, y2, x2, mode2} (crop origin = r % (H - S + 1), mode = 1 + r % 7); sigma: f32 [B] noise
+ * level used when no degraded image is given: clip(gt + z * sigma, 0, 255) truncated to the uint8 grid, z = counter-based N(0, 1) of
+ * (seed[0], site + b, pixel) -- both crops see the SAME noisy image.  Outputs f32 [B][3][S][S] in [0, 1] (ToTensor): degraded crop 1 / 2,
+ * clean crop 1 / 2. */
+int fw_train_batch(const void* tab, const int* rnd, const float* sigma, const void* seed, int site, float* d1, float* d2, float* c1,
+                   float* c2, int B, int S, void* stream);
+/* test.py:47-57: tiles[t = a * nx + b][c][i][j] = img[c][ys[a] + i][xs[b] + j]  (ys / xs: device int32 tile origins) */
+int fw_tile_gather(const float* img, const int* ys, const int* xs, float* tiles, int C, int H, int W, int ny, int nx, int T, void* stream);
+/* test.py:61-71 with the RESTORED tiles: out[c][y][x] = mean of the tiles covering (y, x) */
+int fw_tile_blend(const float* tiles, const int* ys, const int* xs, float* out, int C, int H, int W, int ny, int nx, int T, void* stream);
+/* utils/val_utils.py:50-66 (skimage structural_similarity defaults: 7x7 uniform window, K1 .01, K2 .03, sample covariance, 3-pixel
+ * border cropped, inputs clipped to [0, 1]): out[i] += sum of the SSIM map of image i over channels and interior pixels. */
+int fw_ssim7(const float* a, const float* b, float* out, int n, int C, int H, int W, void* stream);
+
 /* ---- fused LeFF forward (net/utils/leff.py:92-117) for the high-resolution stages, bf16 operands ----------------------------
  * y = res + rowscale * linear2(GELU(dwconv3x3(GELU(linear1(xn))))) in one kernel per 8 x 16 pixel patch: the hidden tensor is
  * produced and consumed on chip (7 chunks of 4C/7 channels); h1, g1, h2, g2 (bf16 [T][4C]) are WRITTEN for the unfused backward

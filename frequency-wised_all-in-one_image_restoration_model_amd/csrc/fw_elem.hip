@@ -154,7 +154,7 @@ template <> struct Raw4<bf16raw> {
 // Branch-free: out-of-image taps are read from CLAMPED coordinates and zeroed by a select, so the 30 (+8) loads of a thread are
 // independent instructions the compiler issues back to back -- with a branch around every edge load each load waited for the
 // previous one (a chain of 30 memory latencies per thread: 2 TB/s instead of the ~5 TB/s this access pattern streams at).
-template <typename T, int MODE>
+template <typename T, int MODE, bool GIN = false>          // GIN: the input is the PRE-activation; GELU is applied as it is consumed
 __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__ in, long ldi, const float* __restrict__ w, const float* __restrict__ bias,
                                     const T* __restrict__ pre, T* __restrict__ out, T* __restrict__ out2, long ldo, int B, int H, int W, int C) {
     constexpr int E = 4;                                   // channels per thread
@@ -207,6 +207,10 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
                 r.zero_unless(row_ok && (cx >= 0 || left_ok) && (cx < SX || right_ok));
                 float f[E];
                 r.unpack(f);
+                if constexpr (GIN) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) f[e] = gelu_t<T>(f[e]);          // GELU(0) = 0: the zero padding stays zero
+                }
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int o = cx - kx + 1;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
 // LDS layout [row][pixel][64 ch], 128-byte pixels, row stride 18 * 128 + 128 (= 128 mod 256: the two rows of a 32-lane half hit
 // disjoint bank halves).  lane = (channel vector 0..15, row 0..7, strip 0..1).
 constexpr int DT_TY = 8, DT_TX = 16, DT_CB = 64;
-template <typename T, int MODE>
+template <typename T, int MODE, bool GIN = false>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(const T* __restrict__ in, long ldi, const float* __restrict__ w, const float* __restrict__ bias,
                                     const T* __restrict__ pre, T* __restrict__ out, T* __restrict__ out2, long ldo, int B, int H, int W, int C) {
     constexpr int SZ = TT<T>::SZ, E16 = TT<T>::E16;
@@ -302,7 +306,15 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const T* __restrict__ 
         const int ch = idx % CHUNKS, px = (idx / CHUNKS) % (DT_TX + 2), row = idx / (CHUNKS * (DT_TX + 2));
         const int yy = y0 + row - 1, xx = x0 + px - 1, cc = c0b + ch * E16;
         const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W && cc + E16 <= C;
-        *reinterpret_cast<uint4*>(dsm + row * ROWB + px * PXB + ch * 16) = ok ? r[i] : make_uint4(0, 0, 0, 0);
+        uint4 piece = r[i];
+        if constexpr (GIN) {                                  // the pre-activation arrives: GELU once per halo element, on its way into LDS
+            float f[E16];
+            unpack16<T>(piece, f);
+#pragma unroll
+            for (int e = 0; e < E16; ++e) f[e] = gelu_t<T>(f[e]);
+            piece = pack16<T>(f);
+        }
+        *reinterpret_cast<uint4*>(dsm + row * ROWB + px * PXB + ch * 16) = ok ? piece : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     // ---- stencil from LDS ----
@@ -346,8 +358,12 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const T* __restrict__ 
 // weight / bias gradient.  block = 8 strip lanes x 32 channel vectors (4 channels each: 256 contiguous bytes per pixel); a thread
 // walks NSTRIP consecutive strips with its 10 x 4 partial sums in registers; partials are folded over the block (one shuffle +
 // LDS) before ONE atomic per word.  Loads are branch-free (clamped coordinates, zeroed by select) so they issue back to back.
+// INPUT-centric: a thread owns 8 INPUT pixels (the activation g1, or -- GIN -- the pre-activation h1, whose GELU is then evaluated
+// exactly once per element) and gathers the 3 x 10 halo of the OUTPUT gradient:
+//     dw[tap (ky, kx)] += g1[y][x] * dh2[y - ky + 1][x - kx + 1]        (dh2 = 0 outside the image)
+// -- the same sum as the output-centric form, which would need GELU on its 3.75x re-read input halo.
 constexpr int WG_VL = 32, WG_SL = 8;
-template <typename T>
+template <typename T, bool GIN>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dh2, long ldg, const T* __restrict__ g1, long ld1,
                                                            float* __restrict__ dw, float* __restrict__ dbias, int B, int H, int W, int C, int NSTRIP) {
     constexpr int E = 4;                                   // channels per thread
@@ -372,42 +388,48 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
             const int x0 = sx * SX;
             const bool left_ok = x0 > 0, right_ok = x0 + SX < W;
             const int xl = left_ok ? x0 - 1 : 0, xr = right_ok ? x0 + SX : W - 1;
-            Raw4<T> rd[SX], raw[3][SX + 2];
-            const T* drow = dh2 + ((b * H + y) * W + x0) * ldg + c0;
+            Raw4<T> rg[SX], raw[3][SX + 2];
+            const T* grow = g1 + ((b * H + y) * W + x0) * ld1 + c0;
 #pragma unroll
-            for (int o = 0; o < SX; ++o) rd[o].load(drow + (long)o * ldg);
+            for (int o = 0; o < SX; ++o) rg[o].load(grow + (long)o * ld1);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                int yy = y + ky - 1;
+                int yy = y - ky + 1;
                 yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
-                const T* row = g1 + ((b * H + yy) * W) * ld1 + c0;
-                raw[ky][0].load(row + (long)xl * ld1);
+                const T* row = dh2 + ((b * H + yy) * W) * ldg + c0;
+                raw[ky][0].load(row + (long)xl * ldg);
 #pragma unroll
-                for (int cx = 0; cx < SX; ++cx) raw[ky][cx + 1].load(row + (long)(x0 + cx) * ld1);
-                raw[ky][SX + 1].load(row + (long)xr * ld1);
+                for (int cx = 0; cx < SX; ++cx) raw[ky][cx + 1].load(row + (long)(x0 + cx) * ldg);
+                raw[ky][SX + 1].load(row + (long)xr * ldg);
             }
-            float d[SX][E];
+            float g[SX][E];
 #pragma unroll
             for (int o = 0; o < SX; ++o) {
-                rd[o].unpack(d[o]);
+                rg[o].unpack(g[o]);
+                if constexpr (GIN) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) gw[9][e] += d[o][e];
+                    for (int e = 0; e < E; ++e) g[o][e] = gelu_t<T>(g[o][e]);
+                }
             }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const bool row_ok = (y + ky - 1 >= 0) && (y + ky - 1 < H);
+                const bool row_ok = (y - ky + 1 >= 0) && (y - ky + 1 < H);
 #pragma unroll
-                for (int cx = -1; cx <= SX; ++cx) {
-                    Raw4<T> r = raw[ky][cx + 1];
-                    r.zero_unless(row_ok && (cx >= 0 || left_ok) && (cx < SX || right_ok));
-                    float f[E];
-                    r.unpack(f);
+                for (int j = 0; j < SX + 2; ++j) {               // dh2 at column x0 - 1 + j
+                    Raw4<T> r = raw[ky][j];
+                    r.zero_unless(row_ok && (j >= 1 || left_ok) && (j <= SX || right_ok));
+                    float d[E];
+                    r.unpack(d);
+                    if (ky == 1 && j >= 1 && j <= SX) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) gw[9][e] += d[e];
+                    }
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int o = cx - kx + 1;
-                        if (o >= 0 && o < SX) {
+                        const int i = j + kx - 2;                // input pixel of the strip: j = i - kx + 2
+                        if (i >= 0 && i < SX) {
 #pragma unroll
-                            for (int e = 0; e < E; ++e) gw[ky * 3 + kx][e] += f[e] * d[o][e];
+                            for (int e = 0; e < E; ++e) gw[ky * 3 + kx][e] += g[i][e] * d[e];
                         }
                     }
                 }
@@ -924,14 +946,14 @@ __global__ void fill_kernel(float* __restrict__ p, long n, float v) {
 #define ST ((hipStream_t)stream)
 static int dw_tiled() { static const int v = getenv("FW_DWCONV_TILED") ? atoi(getenv("FW_DWCONV_TILED")) : 1; return v; }
 static long dw_tiled_min() { static const long v = getenv("FW_DWCONV_TILED_MIN") ? atol(getenv("FW_DWCONV_TILED_MIN")) : 10000000L; return v; }   // elements B*H*W*C from which the LDS-tiled form is used: 272.8 images/s at 80 M (stage 0 only), 273.7 at 20 M, 274.6 at 10 M, 274.0 at 1 M
-template <typename T, int MODE>
+template <typename T, int MODE, bool GIN = false>
 static int dwconv_tile_launch(const T* in, long ldi, const float* w, const float* bias, const T* pre, T* out, T* out2, long ldo, int B, int H, int W,
                               int C, hipStream_t st) {
     const size_t lds = (size_t)(DT_TY + 2) * ((DT_TX + 2) * DT_CB * sizeof(T) + 128);
-    FW_SET_LDS_ONCE((dwconv_tile_kernel<T, MODE>), lds);
+    FW_SET_LDS_ONCE((dwconv_tile_kernel<T, MODE, GIN>), lds);
     long nb = (long)B * (H / DT_TY) * ((W + DT_TX - 1) / DT_TX) * ((C + DT_CB - 1) / DT_CB);
     nb = (nb + 7) / 8 * 8;
-    hipLaunchKernelGGL((dwconv_tile_kernel<T, MODE>), dim3((unsigned)nb), dim3(256), lds, st, in, ldi, w, bias, pre, out, out2, ldo, B, H, W, C);
+    hipLaunchKernelGGL((dwconv_tile_kernel<T, MODE, GIN>), dim3((unsigned)nb), dim3(256), lds, st, in, ldi, w, bias, pre, out, out2, ldo, B, H, W, C);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -972,30 +994,30 @@ extern "C" int fw_permute3(int in_dtype, int out_dtype, const void* in, void* ou
     if (in_dtype == 1 && out_dtype == 0) LAUNCH((permute3_kernel<bf16raw, float>), n, (const bf16raw*)in, (float*)out, d0, d1, d2, s0, s1, s2, accumulate);
     return -1;
 }
-extern "C" int fw_dwconv_fwd(int dtype, const void* g1, long ld1, const float* w, const float* bias, void* h2, void* g2, long ld2,
+extern "C" int fw_dwconv_fwd(int dtype, const void* g1, long ld1, int in_gelu, const float* w, const float* bias, void* h2, void* g2, long ld2,
                              int B, int H, int W, int C, void* stream) {
     const int e = dtype == FW_DT_BF16 ? 8 : 4;
     FW_CHECK_ARG(g1 && w && bias && h2 && g2 && C % e == 0 && ld1 % e == 0 && ld2 % e == 0 && W % SX == 0);
     const long n = (long)B * H * (W / SX) * (C / 4);
     // the LDS-tiled form wins where the tensors outgrow the 256 MB infinity cache (stage-0 layers); below that the strips are as fast
     if (dw_tiled() && H % DT_TY == 0 && (long)B * H * W * C >= dw_tiled_min()) {
-        return dtype == FW_DT_BF16
-            ? dwconv_tile_launch<bf16raw, 0>((const bf16raw*)g1, ld1, w, bias, (const bf16raw*)nullptr, (bf16raw*)h2, (bf16raw*)g2, ld2, B, H, W, C, ST)
-            : dwconv_tile_launch<float, 0>((const float*)g1, ld1, w, bias, (const float*)nullptr, (float*)h2, (float*)g2, ld2, B, H, W, C, ST);
+        if (dtype == FW_DT_BF16)
+            return in_gelu ? dwconv_tile_launch<bf16raw, 0, true>((const bf16raw*)g1, ld1, w, bias, (const bf16raw*)nullptr, (bf16raw*)h2, (bf16raw*)g2, ld2, B, H, W, C, ST)
+                           : dwconv_tile_launch<bf16raw, 0>((const bf16raw*)g1, ld1, w, bias, (const bf16raw*)nullptr, (bf16raw*)h2, (bf16raw*)g2, ld2, B, H, W, C, ST);
+        return in_gelu ? dwconv_tile_launch<float, 0, true>((const float*)g1, ld1, w, bias, (const float*)nullptr, (float*)h2, (float*)g2, ld2, B, H, W, C, ST)
+                       : dwconv_tile_launch<float, 0>((const float*)g1, ld1, w, bias, (const float*)nullptr, (float*)h2, (float*)g2, ld2, B, H, W, C, ST);
     }
     const dim3 grid((unsigned)((grid_for(n) + 7) / 8 * 8));            // multiple of 8: XCD-contiguous block mapping
-    if (dtype == FW_DT_BF16)
-        hipLaunchKernelGGL((dwconv_strip_kernel<bf16raw, 0>), grid, dim3(TPB), 0, ST, (const bf16raw*)g1, ld1, w, bias, (const bf16raw*)nullptr,
-                           (bf16raw*)h2, (bf16raw*)g2, ld2, B, H, W, C);
-    else
-        hipLaunchKernelGGL((dwconv_strip_kernel<float, 0>), grid, dim3(TPB), 0, ST, (const float*)g1, ld1, w, bias, (const float*)nullptr,
-                           (float*)h2, (float*)g2, ld2, B, H, W, C);
+#define FW_STRIP_FWD(TY, GI) hipLaunchKernelGGL((dwconv_strip_kernel<TY, 0, GI>), grid, dim3(TPB), 0, ST, (const TY*)g1, ld1, w, bias, (const TY*)nullptr, (TY*)h2, (TY*)g2, ld2, B, H, W, C)
+    if (dtype == FW_DT_BF16) { if (in_gelu) FW_STRIP_FWD(bf16raw, true); else FW_STRIP_FWD(bf16raw, false); }
+    else { if (in_gelu) FW_STRIP_FWD(float, true); else FW_STRIP_FWD(float, false); }
+#undef FW_STRIP_FWD
     FW_LAUNCH_RET();
 }
 extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g1, const void* h1, long ld1, const float* w, void* dh1,
                              long ldo, float* dw, float* dbias, int B, int H, int W, int C, void* stream) {
     const int e = dtype == FW_DT_BF16 ? 8 : 4;
-    FW_CHECK_ARG(dh2 && g1 && h1 && w && dh1 && dw && dbias && C % e == 0 && ld1 % e == 0 && ldg % e == 0 && ldo % e == 0 && W % SX == 0);
+    FW_CHECK_ARG(dh2 && h1 && w && dh1 && dw && dbias && C % e == 0 && ld1 % e == 0 && ldg % e == 0 && ldo % e == 0 && W % SX == 0);
     FW_CHECK_ARG(ldg == ld1);                      // the data-gradient strip kernel walks dh2 and h1 with one row stride
     const long n = (long)B * H * (W / SX) * (C / 4);
     const int nvg = (C / 4 + WG_VL - 1) / WG_VL;
@@ -1013,14 +1035,17 @@ extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g
             : dwconv_tile_launch<float, 1>((const float*)dh2, ldg, w, (const float*)nullptr, (const float*)h1, (float*)dh1, (float*)nullptr, ldo, B, H, W, C, ST);
         if (rc) return rc;
     }
+    // weight gradient: from the activation g1 when the caller kept it, else from the pre-activation h1 (GELU once per element in-kernel)
     if (dtype == FW_DT_BF16) {
         if (!tiled) hipLaunchKernelGGL((dwconv_strip_kernel<bf16raw, 1>), dim3((grid_for(n) + 7) / 8 * 8), dim3(TPB), 0, ST, (const bf16raw*)dh2, ldg, w, (const float*)nullptr,
                            (const bf16raw*)h1, (bf16raw*)dh1, (bf16raw*)nullptr, ldo, B, H, W, C);
-        hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16raw>), gridw, dim3(256), 0, ST, (const bf16raw*)dh2, ldg, (const bf16raw*)g1, ld1, dw, dbias, B, H, W, C, NSTRIP);
+        if (g1) hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16raw, false>), gridw, dim3(256), 0, ST, (const bf16raw*)dh2, ldg, (const bf16raw*)g1, ld1, dw, dbias, B, H, W, C, NSTRIP);
+        else hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16raw, true>), gridw, dim3(256), 0, ST, (const bf16raw*)dh2, ldg, (const bf16raw*)h1, ld1, dw, dbias, B, H, W, C, NSTRIP);
     } else {
         if (!tiled) hipLaunchKernelGGL((dwconv_strip_kernel<float, 1>), dim3((grid_for(n) + 7) / 8 * 8), dim3(TPB), 0, ST, (const float*)dh2, ldg, w, (const float*)nullptr,
                            (const float*)h1, (float*)dh1, (float*)nullptr, ldo, B, H, W, C);
-        hipLaunchKernelGGL((dwconv_wgrad_kernel<float>), gridw, dim3(256), 0, ST, (const float*)dh2, ldg, (const float*)g1, ld1, dw, dbias, B, H, W, C, NSTRIP);
+        if (g1) hipLaunchKernelGGL((dwconv_wgrad_kernel<float, false>), gridw, dim3(256), 0, ST, (const float*)dh2, ldg, (const float*)g1, ld1, dw, dbias, B, H, W, C, NSTRIP);
+        else hipLaunchKernelGGL((dwconv_wgrad_kernel<float, true>), gridw, dim3(256), 0, ST, (const float*)dh2, ldg, (const float*)h1, ld1, dw, dbias, B, H, W, C, NSTRIP);
     }
     FW_LAUNCH_RET();
 }

@@ -45,6 +45,8 @@ struct GemmArgs {
     float* xsum;                        // optional: xsum[m] += sum_k X(m,k) (x_trans only; the bias gradient of a dW GEMM)
     long c_zstride, xsum_zstride;       // > 0: split-K slice z writes its partial tile / sums to C + z*stride (plain stores, no atomics)
     float alpha;
+    int staged;                         // >= 0: bf16 epilogue through LDS (tile_epilogue_staged mode)
+    int dbg;                            // measurement only (FW_GEMM_BIG_DBG): 1 skip the epilogue's stores, 2 skip the operand loads
 };
 
 constexpr int LDS_ROW = 128;            // 128 B of K per row, XOR-swizzled in 16-byte slots (no padding)
@@ -838,6 +840,88 @@ FW_DEV uint4 frag_sw64(const char* tile, int row0) {
     return *reinterpret_cast<const uint4*>(tile + row * ROW64 + (((l >> 4) ^ swz64(row)) << 4));
 }
 
+// ---- bf16 epilogue through LDS: full 128-byte row segments instead of 8-byte pieces ---------------------------------------------------
+// The MFMA C/D layout hands a lane 4 consecutive n of ONE row: stored directly that is an 8-byte store per lane, 16 rows x 32 bytes per
+// wave instruction -- the store path takes them at ~7 B/clk/CU (cdna_hip_programming.md T21), and with the operand loads removed the
+// 256 x 256 kernel still spent 39 of its 71 us in this epilogue (16384 x 1792 x 448 with the GELU twin: tools/big_gemm_bench.py,
+// FW_GEMM_BIG_DBG).  Here a wave parks its [16 * WM rows][64 columns] sub-tile in LDS (its own region: no workgroup barrier; rows
+// padded to 136 bytes, so the 16 lanes of a column group fall on 32 distinct banks) and writes it out as whole 128-byte row segments,
+// 16 bytes per lane, 8 rows per wave instruction.  mode 0: v = acc + bias;  1: also the GELU twin into C2;  2: v * GELU'(aux), the
+// aux operand fetched the same way (row segments -> LDS -> the lane's quad).  Needs bf16 C, N % 8 == 0, ldc % 8 == 0.
+constexpr int EPI_LD = 136;
+template <int WM>
+FW_DEV void tile_epilogue_staged(const GemmArgs& a, const f32x4 (&acc)[4][WM], int m_blk, int n_blk, int wm0, int wn0, char* stage, int mode) {
+    const int l = lane_id();
+    char* mine = stage + (threadIdx.x >> 6) * (16 * WM * EPI_LD);
+    f32x4 bias4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n0 = n_blk + wn0 + nt * 16 + ((l >> 4) << 2);
+        bias4[nt] = epi_bias(a, n0 < a.N ? n0 : 0, 0);
+    }
+    const int rsub = l >> 3, cb = (l & 7) * 16;                   // row-segment form: lane = (row in a group of 8, 16-byte chunk of the 128-byte segment)
+    const int ncol = n_blk + wn0 + (l & 7) * 8;                   // first of the lane's 8 columns
+    const bool col_ok = ncol < a.N;
+    auto rows_out = [&](char* C, long ldc) {                      // LDS region -> global, whole row segments
+#pragma unroll
+        for (int it = 0; it < 2 * WM; ++it) {
+            const int r = it * 8 + rsub, m = m_blk + wm0 + r;
+            const uint4 v = *reinterpret_cast<const uint4*>(mine + r * EPI_LD + cb);
+            if (m < a.M && col_ok) *reinterpret_cast<uint4*>(C + ((long)m * ldc + ncol) * 2) = v;
+        }
+    };
+    if (mode == 2) {                                              // aux rows in: global row segments -> LDS
+#pragma unroll
+        for (int it = 0; it < 2 * WM; ++it) {
+            const int r = it * 8 + rsub, m = m_blk + wm0 + r;
+            const long mc = m < a.M ? m : a.M - 1;
+            const uint4 v = *reinterpret_cast<const uint4*>(a.aux + (mc * a.ldaux + (col_ok ? ncol : 0)) * 2);
+            *reinterpret_cast<uint4*>(mine + r * EPI_LD + cb) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && mode != 1) break;
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+            char* rowp = mine + (mt * 16 + (l & 15)) * EPI_LD + ((l >> 4) << 3);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 v = acc[nt][mt] + bias4[nt];
+                if (mode == 2) {
+                    const uint2 e = *reinterpret_cast<const uint2*>(rowp + nt * 32);
+                    v[0] *= gelu_grad_poly(__uint_as_float(e.x << 16)); v[1] *= gelu_grad_poly(__uint_as_float(e.x & 0xffff0000u));
+                    v[2] *= gelu_grad_poly(__uint_as_float(e.y << 16)); v[3] *= gelu_grad_poly(__uint_as_float(e.y & 0xffff0000u));
+                } else if (pass == 1) {
+                    v[0] = gelu_poly(v[0]); v[1] = gelu_poly(v[1]); v[2] = gelu_poly(v[2]); v[3] = gelu_poly(v[3]);
+                }
+                *reinterpret_cast<uint2*>(rowp + nt * 32) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (pass == 0) rows_out(a.C, a.ldc); else rows_out(a.C2, a.ldc2);
+        if (pass == 0 && mode == 1) {                             // the twin pass rewrites the region: the reads above must have returned
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+// which staged mode serves this launch (-1: none)
+static inline int staged_mode(const GemmArgs& a) {
+    if (a.out_f32 || a.alpha != 1.0f || a.rowscale || a.residual || a.accumulate || a.c_zstride || a.splitk != 1 || a.N % 8 || a.ldc % 8) return -1;
+    if (((uintptr_t)a.C & 15)) return -1;
+    if (a.act == 0 && !a.C2) return 0;
+    if (a.act == 0 && a.C2) return (a.ldc2 % 8 || ((uintptr_t)a.C2 & 15)) ? -1 : 1;
+    if (a.act == 2 && !a.C2) return (a.ldaux % 8 || ((uintptr_t)a.aux & 15)) ? -1 : 2;
+    return -1;
+}
+
 template <bool XT, int KT, int NS, bool PLAIN>
 __global__ __launch_bounds__(256, (KT == 32 && NS == 3) ? 3 : 2) void gemm_tr_ring_kernel(GemmArgs a) {
     using T = bf16raw;
@@ -939,6 +1023,11 @@ __global__ __launch_bounds__(256, (KT == 32 && NS == 3) ? 3 : 2) void gemm_tr_ri
             }
         }
     }
+    if (a.staged >= 0 && (size_t)NS * STAGE >= (size_t)4 * 16 * WM * EPI_LD) {
+        __syncthreads();                                   // every wave has left the ring: its space stages the output rows
+        tile_epilogue_staged<WM>(a, acc, m_blk, n_blk, wm0, wn0, smem, a.staged);
+        return;
+    }
     tile_epilogue<T, WM, PLAIN>(a, acc, m_blk, n_blk, wm0, wn0, bz);
 }
 
@@ -1030,7 +1119,13 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs a) {
         }
         buf = buf + 1 == NS ? 0 : buf + 1;
     }
-    const int l = lane_id();
+    if constexpr (sizeof(T) == 2) {
+        if (a.staged >= 0 && (size_t)NS * STAGE >= (size_t)4 * 16 * WM * EPI_LD) {
+            __syncthreads();
+            tile_epilogue_staged<WM>(a, acc, m_blk, n_blk, wm0, wn0, smem, a.staged);
+            return;
+        }
+    }
     tile_epilogue<T, WM, PLAIN>(a, acc, m_blk, n_blk, wm0, wn0, bz);
 }
 
@@ -1126,6 +1221,13 @@ __global__ __launch_bounds__(256) void gemm_ring64_kernel(GemmArgs a) {
             for (int n = 0; n < WM; ++n) mma_chunk<T>(acc[m][n], af[m], bfr[n]);
         buf = buf + 1 == NS ? 0 : buf + 1;
     }
+    if constexpr (sizeof(T) == 2) {
+        if (a.staged >= 0 && (size_t)NS * STAGE >= (size_t)4 * 16 * WM * EPI_LD) {
+            __syncthreads();
+            tile_epilogue_staged<WM>(a, acc, m_blk, n_blk, wm0, wn0, smem, a.staged);
+            return;
+        }
+    }
     tile_epilogue<T, WM, PLAIN>(a, acc, m_blk, n_blk, wm0, wn0, bz);
 }
 
@@ -1141,6 +1243,153 @@ int launch_ring64_p(const GemmArgs& a, hipStream_t st) {
 template <typename T, int BN, int NS>
 int launch_ring64(const GemmArgs& a, hipStream_t st) {
     return plain_epilogue(a) ? launch_ring64_p<T, BN, NS, true>(a, st) : launch_ring64_p<T, BN, NS, false>(a, st);
+}
+
+// ---- 256 x 256 tiles, 8 waves: the compute-bound products (C = 448 / 896 stages, the 65 536-wide encoder heads) --------------------
+// The 128 x 128 rings above move (128 + 128) x K operand bytes per 128 x 128 outputs through the CU's L2 port; at K = 448 .. 896 and
+// N >= 1344 they sit at 350 .. 500 TFLOP/s with ~28 GB/s per CU of operand traffic -- bound by bytes in flight per CU, not by the
+// MFMA pipe (1.5 us of MFMA per 21 us tile).  A 256 x 256 tile does four times the products on twice the bytes: wave w (of 8,
+// two per SIMD) owns 128 rows (m) x 64 columns (n) = 32 accumulator tiles (128 VGPRs), a K chunk is 12 fragment reads for 32 MFMAs
+// (16 for 32 before).  Same ring discipline as gemm_ring_kernel (LDS-DMA from inline asm, counted vmcnt, one raw barrier per stage):
+//   KT = 64: 2 stages x 64 KB (128-byte rows);   KT = 32: NS stages x 32 KB (64-byte rows, three stages in flight at NS = 4).
+// WT: W stored [K][N] (input gradients dX = dY W): its tile is two [KT][128] token-major images read with ds_read_b64_tr_b16.
+template <int KT, int NS, bool WT, bool PLAIN>
+__global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs a) {
+    using T = bf16raw;
+    constexpr int WM = 8, BIG = 256;
+    constexpr int XB = BIG * (KT == 64 ? LDS_ROW : ROW64), WB = WT ? 2 * KT * 256 : XB, STAGE = XB + WB;
+    constexpr int NIX = KT == 64 ? 4 : 2, NIW = WT ? KT / 16 : NIX, LPS = NIX + NIW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto xs = [&](int i) -> char* { return smem + i * STAGE; };
+    auto ws = [&](int i) -> char* { return smem + i * STAGE + XB; };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.y > 1) {                                   // XCD-contiguous, banded tile order (see gemm_kernel)
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned w = xcd_contiguous(lin, total);
+        const unsigned per_band = 8 * gridDim.y;
+        const unsigned band = w / per_band, first = band * 8;
+        const unsigned gsz = min(gridDim.x - first, 8u);
+        bx = (int)(first + (w % per_band) % gsz);
+        by = (int)((w % per_band) / gsz);
+    }
+    const int m_blk = bx * BIG, n_blk = by * BIG;
+    const int wm0 = (wave & 1) * 128, wn0 = (wave >> 1) * 64;
+    const int nsteps = a.K / KT;
+
+    // per-thread LDS-DMA sources of stage 0 (a later stage adds its K offset) and destinations inside a stage
+    const char* xsrc[NIX]; int xoff[NIX];
+    const char* wsrc[NIW]; int woff[NIW];
+    long wkstride = 0;
+#pragma unroll
+    for (int it = 0; it < NIX; ++it) {
+        if constexpr (KT == 64) {
+            const int R0 = (wave * NIX + it) * 8, r = R0 + (lane >> 3), p = lane & 7;
+            int gr = m_blk + r; if (gr >= a.M) gr = a.M - 1;
+            xsrc[it] = a.X + (long)gr * a.ldx * 2 + ((p ^ (swz(r) >> 4)) << 4);
+            xoff[it] = R0 * LDS_ROW;
+        } else {
+            const int R0 = (wave * NIX + it) * 16, r = R0 + (lane >> 2), p = lane & 3;
+            int gr = m_blk + r; if (gr >= a.M) gr = a.M - 1;
+            xsrc[it] = a.X + (long)gr * a.ldx * 2 + ((p ^ swz64(r)) << 4);
+            xoff[it] = R0 * ROW64;
+        }
+    }
+    if constexpr (!WT) {
+#pragma unroll
+        for (int it = 0; it < NIW; ++it) {
+            if constexpr (KT == 64) {
+                const int R0 = (wave * NIW + it) * 8, r = R0 + (lane >> 3), p = lane & 7;
+                int gr = n_blk + r; if (gr >= a.N) gr = a.N - 1;
+                wsrc[it] = a.W + (long)gr * a.ldw * 2 + ((p ^ (swz(r) >> 4)) << 4);
+                woff[it] = R0 * LDS_ROW;
+            } else {
+                const int R0 = (wave * NIW + it) * 16, r = R0 + (lane >> 2), p = lane & 3;
+                int gr = n_blk + r; if (gr >= a.N) gr = a.N - 1;
+                wsrc[it] = a.W + (long)gr * a.ldw * 2 + ((p ^ swz64(r)) << 4);
+                woff[it] = R0 * ROW64;
+            }
+        }
+    } else {
+        // waves 0-3 fill the [KT][128] image of columns n_blk .. +127, waves 4-7 that of n_blk + 128 .. +255 (4 token rows per instruction)
+        const int half = wave >> 2, wq = wave & 3;
+        wkstride = a.ldw * 2;
+#pragma unroll
+        for (int it = 0; it < NIW; ++it) {
+            const int R0 = wq * (KT / 4) + it * 4, r = R0 + (lane >> 4), p = lane & 15;
+            int col = n_blk + half * 128 + ((p ^ swz256(r)) << 3);
+            if (col >= a.N) col = 0;
+            wsrc[it] = a.W + ((long)r * a.ldw + col) * 2;
+            woff[it] = half * KT * 256 + R0 * 256;
+        }
+    }
+    auto issue = [&](int step, int buf) {
+        char* xt = xs(buf); char* wt = ws(buf);
+#pragma unroll
+        for (int it = 0; it < NIX; ++it) glds16_asm(xsrc[it] + (long)step * KT * 2, xt + xoff[it]);
+#pragma unroll
+        for (int it = 0; it < NIW; ++it) glds16_asm(wsrc[it] + (WT ? (long)step * KT * wkstride : (long)step * KT * 2), wt + woff[it]);
+    };
+    f32x4 acc[4][WM];
+    zero_acc(acc);
+    const bool noload = a.dbg & 2;
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nsteps && !noload) issue(p, p);
+    int buf = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const int younger = min(NS - 2, nsteps - 1 - s);
+        if (younger >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
+        else if (NS >= 4 && younger == NS - 3) wait_vmcnt<(NS >= 4 ? NS - 3 : 0) * LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NS - 1 < nsteps && !noload) issue(s + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+        const char* xt = xs(buf); const char* wt = ws(buf);
+#pragma unroll
+        for (int c = 0; c < KT / 32; ++c) {
+            uint4 af[4], bfr[WM];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if constexpr (WT) af[m] = frag_tr256(wt + (wn0 >> 7) * KT * 256, (wn0 & 127) + 16 * m, c);
+                else af[m] = KT == 64 ? frag_sw(wt, wn0 + 16 * m, c) : frag_sw64(wt, wn0 + 16 * m);
+            }
+#pragma unroll
+            for (int n = 0; n < WM; ++n) bfr[n] = KT == 64 ? frag_sw(xt, wm0 + 16 * n, c) : frag_sw64(xt, wm0 + 16 * n);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < WM; ++n) mma_chunk<T>(acc[m][n], af[m], bfr[n]);
+        }
+        buf = buf + 1 == NS ? 0 : buf + 1;
+    }
+    if ((a.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+    if (a.staged >= 0) {
+        __syncthreads();                                   // every wave has left the ring: its space stages the output rows
+        tile_epilogue_staged<WM>(a, acc, m_blk, n_blk, wm0, wn0, smem, a.staged);
+        return;
+    }
+    tile_epilogue<T, WM, PLAIN>(a, acc, m_blk, n_blk, wm0, wn0, 0);
+}
+
+template <int KT, int NS, bool WT, bool PLAIN>
+int launch_big_p(const GemmArgs& a, hipStream_t st) {
+    size_t lds = (size_t)NS * (256 * (KT == 64 ? LDS_ROW : ROW64) + (WT ? 2 * KT * 256 : 256 * (KT == 64 ? LDS_ROW : ROW64)));
+    if (lds < (size_t)8 * 128 * EPI_LD) lds = (size_t)8 * 128 * EPI_LD;       // the staged epilogue's 8 x [128][136 B] regions
+    FW_SET_LDS_ONCE((gemm_big_kernel<KT, NS, WT, PLAIN>), lds);
+    FW_KNAME("gemm_big_kernel<%d,%d,%s,%s>", KT, NS, FW_B(WT), FW_B(PLAIN));
+    hipLaunchKernelGGL((gemm_big_kernel<KT, NS, WT, PLAIN>), dim3(fw_cdiv(a.M, 256), fw_cdiv(a.N, 256), 1), dim3(512), lds, st, a);
+    FW_LAUNCH_RET();
+}
+template <bool WT>
+int launch_big(const GemmArgs& a, hipStream_t st) {
+    // FW_GEMM_BIG: 0 off, 1 = 64-deep steps / 2 stages (default), 2 = 32-deep / 4 stages, 3 = 32-deep / 3 stages
+    static const int mode = getenv("FW_GEMM_BIG") ? atoi(getenv("FW_GEMM_BIG")) : 1;
+    const bool pl = plain_epilogue(a);
+    if (mode == 2) return pl ? launch_big_p<32, 4, WT, true>(a, st) : launch_big_p<32, 4, WT, false>(a, st);
+    if (mode == 3) return pl ? launch_big_p<32, 3, WT, true>(a, st) : launch_big_p<32, 3, WT, false>(a, st);
+    return pl ? launch_big_p<64, 2, WT, true>(a, st) : launch_big_p<64, 2, WT, false>(a, st);
 }
 
 template <bool XT>
@@ -1512,12 +1761,24 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
     FW_CHECK_ARG(!C2 || (((uintptr_t)C2 & (4 * sz - 1)) == 0 && ldc2 % 4 == 0));
     a.kper = fw_cdiv(fw_cdiv(K, kt), splitk) * kt;
     a.alpha = alpha;
+    static const int use_staged = getenv("FW_GEMM_STAGED") ? atoi(getenv("FW_GEMM_STAGED")) : 1;
+    a.staged = use_staged ? staged_mode(a) : -1;
+    static const int dbg = getenv("FW_GEMM_BIG_DBG") ? atoi(getenv("FW_GEMM_BIG_DBG")) : 0;
+    a.dbg = dbg;
     hipStream_t st = (hipStream_t)stream;
     // tall-skinny products stream X past a W panel held in LDS (gemm_stream_kernel)
     static const long stream_min_m = getenv("FW_GEMM_STREAM_MIN_M") ? atol(getenv("FW_GEMM_STREAM_MIN_M")) : 32768;
     if (!x_trans && splitk == 1 && !accumulate && x_op == 0 && w_op == 0 && !xsum && K * sz <= 512 && M >= stream_min_m) {
         g_last_variant = 200000 + (w_trans ? 1 : 0);
         return dtype == FW_DT_BF16 ? dispatch_stream<bf16raw>(a, w_trans, st) : dispatch_stream<float>(a, w_trans, st);
+    }
+    // compute-bound shapes on 256 x 256 tiles: at least 160 tiles (most of the 256 CUs busy in the only or last round)
+    static const int big = getenv("FW_GEMM_BIG") ? atoi(getenv("FW_GEMM_BIG")) : 1;
+    static const long big_min_tiles = getenv("FW_GEMM_BIG_MIN_TILES") ? atol(getenv("FW_GEMM_BIG_MIN_TILES")) : 160;
+    if (big && dtype == FW_DT_BF16 && !x_trans && x_op == 0 && w_op == 0 && !xsum && splitk == 1 && !accumulate && K % 64 == 0 && K >= 256 &&
+        ldx % 8 == 0 && ldw % 8 == 0 && (long)fw_cdiv(M, 256) * fw_cdiv(N, 256) >= big_min_tiles) {
+        g_last_variant = 300000 + (w_trans ? 1 : 0);
+        return w_trans ? launch_big<true>(a, st) : launch_big<false>(a, st);
     }
     // bf16 products whose W is stored [K][N] (weight gradients: X token-major too; input gradients: X k-contiguous), whole
     // 64-deep K steps: W (and X) tiles go to LDS as they are and are read with transposing LDS reads (gemm_tr_kernel)

@@ -512,8 +512,9 @@ class WindowAttnFn(torch.autograd.Function):
 # LeFF depthwise conv (input and output are pre-activations; GELU is applied on load by the consumers)
 # ---------------------------------------------------------------------------------------------------------------
 class DwConvFn(torch.autograd.Function):
-    """(h1, g1 = GELU(h1)) -> (h2, g2 = GELU(h2)).  Gradients flow through the pre-activations only: backward receives
-    d h2 (LinearFn routes it there via x_pre) and returns d h1."""
+    """(h1[, g1 = GELU(h1)]) -> (h2, g2 = GELU(h2)).  Gradients flow through the pre-activations only: backward receives
+    d h2 (LinearFn routes it there via x_pre) and returns d h1.  g1 = None (the default path): GELU(h1) is evaluated inside the
+    kernels as the input tile is staged -- forward AND weight gradient -- so that activation never travels through HBM."""
 
     @staticmethod
     def forward(ctx, h1, g1, weight, bias, B, H, W, fuse=None):
@@ -525,8 +526,12 @@ class DwConvFn(torch.autograd.Function):
         else:
             h2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
             g2 = act_empty(h1.shape[0], C, h1.dtype, h1.device)
-            call('fw_dwconv_fwd', dt(h1.dtype), g1, g1.stride(0), wt, bias, h2, g2, h2.stride(0), B, H, W, C)
-        ctx.save_for_backward(h1, g1, weight, wt)
+            src = g1 if g1 is not None else h1
+            call('fw_dwconv_fwd', dt(h1.dtype), src, src.stride(0), int(g1 is None), wt, bias, h2, g2, h2.stride(0), B, H, W, C)
+        if g1 is not None:
+            ctx.save_for_backward(h1, weight, wt, g1)
+        else:
+            ctx.save_for_backward(h1, weight, wt)
         ctx.bias = bias
         ctx.geo = (B, H, W)
         ctx.mark_non_differentiable(g2)
@@ -536,7 +541,8 @@ class DwConvFn(torch.autograd.Function):
     def backward(ctx, dh2, _):
         if dh2 is None:
             return (None,) * 8
-        h1, g1, weight, wt = ctx.saved_tensors
+        h1, weight, wt = ctx.saved_tensors[:3]
+        g1 = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
         B, H, W = ctx.geo
         C = h1.shape[1]
         dh2 = aligned(dh2)

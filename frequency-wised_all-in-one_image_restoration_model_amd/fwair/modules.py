@@ -74,7 +74,10 @@ class LeFF(nn.Module):
             # keep their backward passes, only their forward launches collapse into the first one
             fuse = dict(geo=(batch, h, h), residual=residual, rowscale=rowscale, rows_per_scale=h * h, wd=self.conv[0].weight,
                         bd=self.conv[0].bias, w2=self.linear2[0].weight, b2=self.linear2[0].bias)
-        h1, g1 = Fn.linear(xn, self.linear1[0].weight, self.linear1[0].bias, gelu_out=True, fuse=fuse)
+        if fuse is not None:
+            h1, g1 = Fn.linear(xn, self.linear1[0].weight, self.linear1[0].bias, gelu_out=True, fuse=fuse)
+        else:                                      # g1 = GELU(h1) is never materialised: the depthwise kernels apply it on load
+            h1, g1 = Fn.linear(xn, self.linear1[0].weight, self.linear1[0].bias), None
         h2, g2 = Fn.DwConvFn.apply(h1, g1, self.conv[0].weight, self.conv[0].bias, batch, h, h, fuse)
         return Fn.linear(g2, self.linear2[0].weight, self.linear2[0].bias, residual=residual, rowscale=rowscale,
                          rows_per_scale=h * h, x_pre=h2, fuse=fuse)
@@ -82,8 +85,8 @@ class LeFF(nn.Module):
     def forward(self, x):                       # API parity: [B, HW, C] f32 -> [B, HW, C]
         B, HW, C = x.shape
         xn = Fn.CastFn.apply(x.reshape(B * HW, C))
-        h1, g1 = Fn.linear(xn, self.linear1[0].weight, self.linear1[0].bias, gelu_out=True)
-        h2, g2 = Fn.DwConvFn.apply(h1, g1, self.conv[0].weight, self.conv[0].bias, B, int(math.isqrt(HW)), int(math.isqrt(HW)))
+        h1 = Fn.linear(xn, self.linear1[0].weight, self.linear1[0].bias)
+        h2, g2 = Fn.DwConvFn.apply(h1, None, self.conv[0].weight, self.conv[0].bias, B, int(math.isqrt(HW)), int(math.isqrt(HW)))
         y = Fn.linear(g2, self.linear2[0].weight, self.linear2[0].bias, x_pre=h2, out_f32=True)
         return y.view(B, HW, C)
 

@@ -250,14 +250,15 @@ def rel_index(device):
 
 
 # ------------------------------------------------------------------------------------------------ LeFF dwconv
-def dwconv_fwd(g1, w, bias, B, H, W):
-    """w: f32 tap-major [9, C].  -> (h2, g2 = GELU(h2))"""
-    h2, g2 = torch.empty_like(g1), torch.empty_like(g1)
-    call('fw_dwconv_fwd', dt(g1.dtype), g1, _ld(g1), w, bias, h2, g2, _ld(h2), B, H, W, g1.shape[1])
+def dwconv_fwd(src, w, bias, B, H, W, in_gelu=False):
+    """w: f32 tap-major [9, C].  src = g1, or (in_gelu) the pre-activation h1.  -> (h2, g2 = GELU(h2))"""
+    h2, g2 = torch.empty_like(src), torch.empty_like(src)
+    call('fw_dwconv_fwd', dt(src.dtype), src, _ld(src), int(in_gelu), w, bias, h2, g2, _ld(h2), B, H, W, src.shape[1])
     return h2, g2
 
 
 def dwconv_bwd(dh2, g1, h1, w, dw, dbias, B, H, W):
+    """g1 may be None: the weight gradient then evaluates GELU(h1) itself."""
     dh1 = torch.empty_like(h1)
     call('fw_dwconv_bwd', dt(h1.dtype), dh2, _ld(dh2), g1, h1, _ld(h1), w, dh1, _ld(dh1), dw, dbias, B, H, W, h1.shape[1])
     return dh1

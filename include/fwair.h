@@ -88,11 +88,14 @@ int fw_attn_bwd(int dtype, int D, int nkt, int lfs, const void* q, const void* k
                 const void* lfs_tab, void* dq, void* dk, void* dv, void* dk2, void* dv2, long ldd, float* dbias,
                 float* dcoef, int B, int H, int W, int heads, int L, int mode, int shift, float scale, int dq_pad, void* stream);
 
-/* ---- LeFF depthwise 3x3 (net/utils/leff.py:104-111).  Both pre-activations (h) and GELU outputs (g) are kept:
- * fwd: h2 = dwconv(g1) + bias, g2 = GELU(h2);  bwd: dh1 = GELU'(h1) * convT(dh2), dw/dbias accumulated.
+/* ---- LeFF depthwise 3x3 (net/utils/leff.py:104-111).
+ * fwd: h2 = dwconv(GELU?(in)) + bias, g2 = GELU(h2).  in_gelu = 1: `in` is the PRE-activation h1 of linear1 and its GELU (leff.py:100) is
+ * evaluated as the input tile is staged -- the activation g1 = GELU(h1) is then never written to HBM; in_gelu = 0: `in` is g1.
+ * bwd: dh1 = GELU'(h1) * convT(dh2), dw / dbias accumulated; g1 may be NULL: the weight gradient then takes GELU(h1) in-kernel
+ * (input-centric form: exactly one GELU per element).
  * w is TAP-MAJOR f32 [9][C] (a per-step permuted copy of the [C,1,3,3] parameter); dw is ACCUMULATED into in the
  * parameter's own [C][9] layout, dbias likewise ([C]). */
-int fw_dwconv_fwd(int dtype, const void* g1, long ld1, const float* w, const float* bias, void* h2, void* g2, long ld2, int B,
+int fw_dwconv_fwd(int dtype, const void* in, long ld1, int in_gelu, const float* w, const float* bias, void* h2, void* g2, long ld2, int B,
                   int H, int W, int C, void* stream);
 int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g1, const void* h1, long ld1, const float* w, void* dh1,
                   long ldo, float* dw, float* dbias, int B, int H, int W, int C, void* stream);

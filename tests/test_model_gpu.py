@@ -205,9 +205,11 @@ def test_graph_steps_survive_eval_and_empty_cache():
     la, eva, pa = run(True)
     lb, evb, pb = run(False)
     assert torch.isfinite(la).all() and torch.isfinite(pa).all()
-    close(la, lb, 2e-3, 'losses graph vs eager across an eval + empty_cache')
-    close(eva, evb, 2e-3, 'eval output between the steps')
-    close(pa, pb, 2e-3, 'parameters after the fourth step')
+    # bf16 + Adam: a gradient that is ~0 may change sign between two runs (float atomics), and Adam turns either sign into a full
+    # +-lr step -- two correct runs differ by up to 2 lr per parameter and step; a stale / freed operand copy gives errors of O(1) or NaN
+    close(la, lb, 5e-3, 'losses graph vs eager across an eval + empty_cache')
+    close(eva, evb, 2e-2, 'eval output between the steps')
+    assert float((pa - pb).abs().max()) <= 4 * 2 * 1e-3 + 1e-6, 'parameters after the fourth step'
 
 
 def test_256_resolution_fp32_and_bf16():

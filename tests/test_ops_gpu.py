@@ -51,8 +51,8 @@ def q(t, dtype):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('M,N,K', [(300, 168, 56), (1024, 256, 448), (640, 56, 224), (200, 84, 32), (128, 3584, 896), (16400, 392, 224)])
-def test_gemm_nt_epilogues(dtype, M, N, K):      # the last shape: >= 384 tiles of 128 x 128 with K = 224 -> gemm_ring64_kernel
+@pytest.mark.parametrize('M,N,K', [(300, 168, 56), (1024, 256, 448), (640, 56, 224), (200, 84, 32), (128, 3584, 896), (16400, 392, 224), (4000, 2692, 448)])
+def test_gemm_nt_epilogues(dtype, M, N, K):      # (16400, 392, 224): >= 384 tiles of 128 x 128 with K = 224 -> gemm_ring64_kernel; the last: 176 tiles of 256 x 256 with ragged edges -> gemm_big_kernel
     x, w = q(rnd(M, K), dtype), q(rnd(N, K, seed=1) * 0.1, dtype)
     bias, res = rnd(N, seed=2), rnd(M, N, seed=3)
     rows_per = 100
@@ -103,11 +103,12 @@ def test_gemm_c28_padded_rows(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('M,N,K', [(300, 56, 168), (1024, 448, 256), (512, 224, 56), (12300, 508, 192), (8200, 508, 224)])
+@pytest.mark.parametrize('M,N,K', [(300, 56, 168), (1024, 448, 256), (512, 224, 56), (12300, 508, 192), (8200, 508, 224), (4000, 2692, 448)])
 def test_gemm_nn_dx(dtype, M, N, K):
     """dX[M,N] = dY[M,K] @ W[K,N]  (W stored [K][N] -> w_trans).  The last shape (>= 384 tiles, K % 64 == 0) takes the bf16
     kernel that reads W with transposing LDS reads (gemm_tr_ring_kernel<false, 64, ..>), including its GELU' epilogue and bf16 output;
-    the one after it (K = 224: a multiple of 32 only) the 32-deep form with X in 64-byte LDS rows (gemm_tr_ring_kernel<false, 32, 4>)."""
+    the one after it (K = 224: a multiple of 32 only) the 32-deep form with X in 64-byte LDS rows (gemm_tr_ring_kernel<false, 32, 4>); the last
+    (176 ragged tiles of 256 x 256) the 8-wave kernel with W as two token-major images (gemm_big_kernel<.., true, ..>)."""
     dy, w = q(rnd(M, K), dtype), q(rnd(K, N, seed=1) * 0.1, dtype)
     ldn = (N + 7) // 8 * 8
     wp = torch.full((K, ldn), float('nan')); wp[:, :N] = w
@@ -305,8 +306,11 @@ def test_attention_encoder(dtype, L, mode, shift):
 
 
 # ------------------------------------------------------------------------------------------------ LeFF dwconv
+@pytest.mark.parametrize('twin', [True, False])
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_dwconv(dtype):
+def test_dwconv(dtype, twin):
+    """twin: the caller kept g1 = GELU(h1); else (the model's path) the kernels take the pre-activation h1 and apply GELU on load --
+    the forward stencil and the input-centric weight gradient."""
     B, H, W, C = 2, 16, 16, 112
     h1 = q(rnd(B * H * W, C), dtype).requires_grad_(True)
     w = (rnd(C, 1, 3, 3, seed=1) * 0.3).requires_grad_(True)
@@ -314,13 +318,16 @@ def test_dwconv(dtype):
     g1 = q(F.gelu(h1.detach()), dtype)                       # the stored post-activation twin (rounded like the kernel stores it)
     ref = F.conv2d(F.gelu(h1).view(B, H, W, C).permute(0, 3, 1, 2), w, b, padding=1, groups=C).permute(0, 2, 3, 1).reshape(B * H * W, C)
     wt = w.detach().view(C, 9).t().contiguous().to(DEV)                 # tap-major [9, C]
-    h2, g2 = ops().dwconv_fwd(g1.to(DEV, dtype), wt, b.detach().to(DEV), B, H, W)
+    if twin:
+        h2, g2 = ops().dwconv_fwd(g1.to(DEV, dtype), wt, b.detach().to(DEV), B, H, W)
+    else:
+        h2, g2 = ops().dwconv_fwd(h1.detach().to(DEV, dtype), wt, b.detach().to(DEV), B, H, W, in_gelu=True)
     close(h2, ref, TOL[dtype], 'h2')
     close(g2, F.gelu(ref), TOL[dtype], 'g2')
     dh2 = q(rnd(B * H * W, C, seed=3), dtype)
     ref.backward(dh2)
     dw, db = torch.zeros(C, 9, device=DEV), torch.zeros(C, device=DEV)
-    dh1 = ops().dwconv_bwd(dh2.to(DEV, dtype), g1.to(DEV, dtype), h1.detach().to(DEV, dtype), wt, dw, db, B, H, W)
+    dh1 = ops().dwconv_bwd(dh2.to(DEV, dtype), g1.to(DEV, dtype) if twin else None, h1.detach().to(DEV, dtype), wt, dw, db, B, H, W)
     close(dh1, h1.grad, TOL[dtype] * 2, 'dh1')
     close(dw, w.grad.view(C, 9), TOL[dtype] * 2, 'dw')
     close(db, b.grad, TOL[dtype] * 2, 'db')
@@ -710,13 +717,13 @@ def test_dwconv_tiled_kernel_timed_shape(dtype):
     g1 = q(F.gelu(h1.detach()), dtype)
     ref = F.conv2d(F.gelu(h1).view(B, H, W, C).permute(0, 3, 1, 2), w, b, padding=1, groups=C).permute(0, 2, 3, 1).reshape(B * H * W, C)
     wt = w.detach().view(C, 9).t().contiguous().to(DEV)
-    h2, g2 = ops().dwconv_fwd(g1.to(DEV, dtype), wt, b.detach().to(DEV), B, H, W)
+    h2, g2 = ops().dwconv_fwd(h1.detach().to(DEV, dtype), wt, b.detach().to(DEV), B, H, W, in_gelu=True)      # the model's path: GELU while the halo tile is staged
     close(h2, ref, TOL[dtype], 'h2 (tiled kernel)')
     close(g2, F.gelu(ref.detach()), TOL[dtype], 'g2 (tiled kernel)')
     dh2 = q(rnd(B * H * W, C, seed=3), dtype)
     ref.backward(dh2)
     dw, db = torch.zeros(C, 9, device=DEV), torch.zeros(C, device=DEV)
-    dh1 = ops().dwconv_bwd(dh2.to(DEV, dtype), g1.to(DEV, dtype), h1.detach().to(DEV, dtype), wt, dw, db, B, H, W)
+    dh1 = ops().dwconv_bwd(dh2.to(DEV, dtype), None, h1.detach().to(DEV, dtype), wt, dw, db, B, H, W)
     close(dh1, h1.grad, TOL[dtype] * 2, 'dh1 (tiled kernel)')
     # 262 144 pixels summed per tap: f32 atomics of block partials; bf16 operands carry 8 bits each
     close(dw, w.grad.view(C, 9), TOL[dtype] * 4, 'dw')

@@ -43,8 +43,8 @@ for B, H, C in shapes:
     w = torch.randn(9, C, device=dev)
     b = torch.randn(C, device=dev)
     dw, db = torch.zeros(C, 9, device=dev), torch.zeros(C, device=dev)
-    t1 = timeit(lambda: ops.dwconv_fwd(g1, w, b, B, H, H))
-    t2 = timeit(lambda: ops.dwconv_bwd(dh2, g1, h1, w, dw, db, B, H, H))
+    t1 = timeit(lambda: ops.dwconv_fwd(h1, w, b, B, H, H, in_gelu=True))
+    t2 = timeit(lambda: ops.dwconv_bwd(dh2, None, h1, w, dw, db, B, H, H))
     by1 = rows * C * 2 * 3
     by2 = rows * C * 2 * 5            # data grad: dh2, h1 -> dh1; weight grad: dh2, g1
     print(f'{B:3d} {H:4d} {C:5d} {t1 * 1e6:9.1f} {by1 / t1 / 1e9:6.0f} {t2 * 1e6:9.1f} {by2 / t2 / 1e9:6.0f}')

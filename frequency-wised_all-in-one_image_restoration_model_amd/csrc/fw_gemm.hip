@@ -1373,6 +1373,119 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmArgs a) {
     tile_epilogue<T, WM, PLAIN>(a, acc, m_blk, n_blk, wm0, wn0, 0);
 }
 
+// ---- 128 x 256 tiles, 4 waves, TWO workgroups per CU ------------------------------------------------------------------------------
+// The 256 x 256 kernel runs one workgroup per CU: with the operand loads removed it still spent half its time in the epilogue's
+// stores (tools/big_gemm_bench.py, FW_GEMM_BIG_DBG: 62 us whole, 32 us without stores at 16384 x 1792 x 448), because nothing else
+// runs on the CU while a tile drains.  Same wave tile here (128 rows x 64 columns, 32 accumulator tiles, 12 fragment reads per 32
+// MFMAs), but the workgroup is 4 waves = 128 x 256 outputs on a 3-stage ring of 32-deep steps (72 KB): two workgroups share a CU, and
+// one's store phase runs under the other's K loop.  X tile [128][64 B], W tile [256][64 B] (or two [32][128] token-major images).
+template <int NS, bool WT, bool PLAIN>
+__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(GemmArgs a) {
+    using T = bf16raw;
+    constexpr int KT = 32, WM = 8, TM = 128, TN = 256;
+    constexpr int XB = TM * ROW64, WB = WT ? 2 * KT * 256 : TN * ROW64, STAGE = XB + WB;
+    constexpr int NIX = 2, NIW = 4, LPS = NIX + NIW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto xs = [&](int i) -> char* { return smem + i * STAGE; };
+    auto ws = [&](int i) -> char* { return smem + i * STAGE + XB; };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.y > 1) {
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned w = xcd_contiguous(lin, total);
+        const unsigned per_band = 8 * gridDim.y;
+        const unsigned band = w / per_band, first = band * 8;
+        const unsigned gsz = min(gridDim.x - first, 8u);
+        bx = (int)(first + (w % per_band) % gsz);
+        by = (int)((w % per_band) / gsz);
+    }
+    const int m_blk = bx * TM, n_blk = by * TN;
+    const int wm0 = 0, wn0 = wave * 64;
+    const int nsteps = a.K / KT;
+    const char* xsrc[NIX]; int xoff[NIX];
+    const char* wsrc[NIW]; int woff[NIW];
+    long wkstride = 0;
+#pragma unroll
+    for (int it = 0; it < NIX; ++it) {
+        const int R0 = (wave * NIX + it) * 16, r = R0 + (lane >> 2), p = lane & 3;
+        int gr = m_blk + r; if (gr >= a.M) gr = a.M - 1;
+        xsrc[it] = a.X + (long)gr * a.ldx * 2 + ((p ^ swz64(r)) << 4);
+        xoff[it] = R0 * ROW64;
+    }
+    if constexpr (!WT) {
+#pragma unroll
+        for (int it = 0; it < NIW; ++it) {
+            const int R0 = (wave * NIW + it) * 16, r = R0 + (lane >> 2), p = lane & 3;
+            int gr = n_blk + r; if (gr >= a.N) gr = a.N - 1;
+            wsrc[it] = a.W + (long)gr * a.ldw * 2 + ((p ^ swz64(r)) << 4);
+            woff[it] = R0 * ROW64;
+        }
+    } else {
+        const int half = wave >> 1, wq = wave & 1;          // waves 0-1: columns n_blk .. +127, waves 2-3: the next 128; 16 token rows each
+        wkstride = a.ldw * 2;
+#pragma unroll
+        for (int it = 0; it < NIW; ++it) {
+            const int R0 = wq * 16 + it * 4, r = R0 + (lane >> 4), p = lane & 15;
+            int col = n_blk + half * 128 + ((p ^ swz256(r)) << 3);
+            if (col >= a.N) col = 0;
+            wsrc[it] = a.W + ((long)r * a.ldw + col) * 2;
+            woff[it] = half * KT * 256 + R0 * 256;
+        }
+    }
+    auto issue = [&](int step, int buf) {
+        char* xt = xs(buf); char* wt = ws(buf);
+#pragma unroll
+        for (int it = 0; it < NIX; ++it) glds16_asm(xsrc[it] + (long)step * KT * 2, xt + xoff[it]);
+#pragma unroll
+        for (int it = 0; it < NIW; ++it) glds16_asm(wsrc[it] + (WT ? (long)step * KT * wkstride : (long)step * KT * 2), wt + woff[it]);
+    };
+    f32x4 acc[4][WM];
+    zero_acc(acc);
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nsteps) issue(p, p);
+    int buf = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const int younger = min(NS - 2, nsteps - 1 - s);
+        if (younger >= NS - 2) wait_vmcnt<(NS - 2) * LPS>();
+        else if (NS >= 4 && younger == NS - 3) wait_vmcnt<(NS >= 4 ? NS - 3 : 0) * LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NS - 1 < nsteps) issue(s + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+        const char* xt = xs(buf); const char* wt = ws(buf);
+        uint4 af[4], bfr[WM];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if constexpr (WT) af[m] = frag_tr256(wt + (wn0 >> 7) * KT * 256, (wn0 & 127) + 16 * m, 0);
+            else af[m] = frag_sw64(wt, wn0 + 16 * m);
+        }
+#pragma unroll
+        for (int n = 0; n < WM; ++n) bfr[n] = frag_sw64(xt, wm0 + 16 * n);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < WM; ++n) mma_chunk<T>(acc[m][n], af[m], bfr[n]);
+        buf = buf + 1 == NS ? 0 : buf + 1;
+    }
+    if (a.staged >= 0) {
+        __syncthreads();
+        tile_epilogue_staged<WM>(a, acc, m_blk, n_blk, wm0, wn0, smem, a.staged);
+        return;
+    }
+    tile_epilogue<T, WM, PLAIN>(a, acc, m_blk, n_blk, wm0, wn0, 0);
+}
+template <int NS, bool WT, bool PLAIN>
+int launch_wide_p(const GemmArgs& a, hipStream_t st) {
+    size_t lds = (size_t)NS * (128 * ROW64 + (WT ? 2 * 32 * 256 : 256 * ROW64));
+    if (lds < (size_t)4 * 128 * EPI_LD) lds = (size_t)4 * 128 * EPI_LD;
+    FW_SET_LDS_ONCE((gemm_wide_kernel<NS, WT, PLAIN>), lds);
+    FW_KNAME("gemm_wide_kernel<%d,%s,%s>", NS, FW_B(WT), FW_B(PLAIN));
+    hipLaunchKernelGGL((gemm_wide_kernel<NS, WT, PLAIN>), dim3(fw_cdiv(a.M, 128), fw_cdiv(a.N, 256), 1), dim3(256), lds, st, a);
+    FW_LAUNCH_RET();
+}
+
 template <int KT, int NS, bool WT, bool PLAIN>
 int launch_big_p(const GemmArgs& a, hipStream_t st) {
     size_t lds = (size_t)NS * (256 * (KT == 64 ? LDS_ROW : ROW64) + (WT ? 2 * KT * 256 : 256 * (KT == 64 ? LDS_ROW : ROW64)));
@@ -1384,9 +1497,15 @@ int launch_big_p(const GemmArgs& a, hipStream_t st) {
 }
 template <bool WT>
 int launch_big(const GemmArgs& a, hipStream_t st) {
-    // FW_GEMM_BIG: 0 off, 1 = 64-deep steps / 2 stages (default), 2 = 32-deep / 4 stages, 3 = 32-deep / 3 stages
-    static const int mode = getenv("FW_GEMM_BIG") ? atoi(getenv("FW_GEMM_BIG")) : 1;
+    // FW_GEMM_BIG: 0 off, 1 = 256 x 256, 64-deep steps / 2 stages, 2 = 32-deep / 4 stages, 3 = 32-deep / 3 stages;
+    //              4 = 128 x 256 tiles at two workgroups per CU (gemm_wide_kernel, 3 stages), 5 = the same with 4 stages (one per CU)
+    // default (mode 6): 128 x 256 tiles at two workgroups per CU, except the 65 536-wide encoder heads (N >= 16384: 1 024 tiles of
+    // 256 x 256 -- 95 us against 106 us).  Measured per shape with tools/big_gemm_bench.py (gpurun_out/bgm*.txt of round 3).
+    static const int mode_env = getenv("FW_GEMM_BIG") ? atoi(getenv("FW_GEMM_BIG")) : 6;
+    const int mode = mode_env == 6 ? (a.N >= 16384 ? 1 : 4) : mode_env;
     const bool pl = plain_epilogue(a);
+    if (mode == 4) return pl ? launch_wide_p<3, WT, true>(a, st) : launch_wide_p<3, WT, false>(a, st);
+    if (mode == 5) return pl ? launch_wide_p<4, WT, true>(a, st) : launch_wide_p<4, WT, false>(a, st);
     if (mode == 2) return pl ? launch_big_p<32, 4, WT, true>(a, st) : launch_big_p<32, 4, WT, false>(a, st);
     if (mode == 3) return pl ? launch_big_p<32, 3, WT, true>(a, st) : launch_big_p<32, 3, WT, false>(a, st);
     return pl ? launch_big_p<64, 2, WT, true>(a, st) : launch_big_p<64, 2, WT, false>(a, st);
@@ -1773,7 +1892,7 @@ extern "C" int fw_gemm(int dtype, const void* X, long ldx, int x_trans, int x_op
         return dtype == FW_DT_BF16 ? dispatch_stream<bf16raw>(a, w_trans, st) : dispatch_stream<float>(a, w_trans, st);
     }
     // compute-bound shapes on 256 x 256 tiles: at least 160 tiles (most of the 256 CUs busy in the only or last round)
-    static const int big = getenv("FW_GEMM_BIG") ? atoi(getenv("FW_GEMM_BIG")) : 1;
+    static const int big = getenv("FW_GEMM_BIG") ? atoi(getenv("FW_GEMM_BIG")) : 6;
     static const long big_min_tiles = getenv("FW_GEMM_BIG_MIN_TILES") ? atol(getenv("FW_GEMM_BIG_MIN_TILES")) : 160;
     if (big && dtype == FW_DT_BF16 && !x_trans && x_op == 0 && w_op == 0 && !xsum && splitk == 1 && !accumulate && K % 64 == 0 && K >= 256 &&
         ldx % 8 == 0 && ldw % 8 == 0 && (long)fw_cdiv(M, 256) * fw_cdiv(N, 256) >= big_min_tiles) {

@@ -40,14 +40,16 @@ __global__ __launch_bounds__(1024) void bn_planes_fwd_kernel(const T* __restrict
     const long M = (long)B * P;
     float mean, rstd;
     if (training) {
+        const float pivot = TT<T>::ld(fea + (long)c * P);          // shifted sums: no cancellation when the spread is small against the mean
         float s = 0.f, q = 0.f;
         for (long i = threadIdx.x; i < M; i += blockDim.x) {
-            const float v = TT<T>::ld(fea + ((i / P) * ED + c) * P + i % P);
+            const float v = TT<T>::ld(fea + ((i / P) * ED + c) * P + i % P) - pivot;
             s += v; q += v * v;
         }
         s = block_sum(s, red); q = block_sum(q, red);
-        mean = s / M;
-        const float var = fmaxf(q / M - mean * mean, 0.f);
+        const float md = s / M;
+        mean = pivot + md;
+        const float var = fmaxf(q / M - md * md, 0.f);
         rstd = rsqrtf(var + eps);
         if (threadIdx.x == 0) {
             rmean[c] = rmean[c] * (1.f - momentum) + momentum * mean;

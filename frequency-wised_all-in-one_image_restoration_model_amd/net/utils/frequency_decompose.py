@@ -16,11 +16,28 @@ from fwair import lfs
 from fwair.lib import call
 
 
-def _bands(x, mask, mode, partition=False):
+_panels = {}
+
+
+def _dft_panels(N, device):
+    """f32 [3][N][N]: cos, sin, -sin of 2 pi u i / N (the MFMA decomposition reads them as ready-made fragments from L2)."""
+    key = (N, str(device))
+    if key not in _panels:
+        ang = 2 * math.pi * torch.outer(torch.arange(N, dtype=torch.float64), torch.arange(N, dtype=torch.float64)) / N
+        _panels[key] = torch.stack([torch.cos(ang), torch.sin(ang), -torch.sin(ang)]).float().contiguous().to(device)
+    return _panels[key]
+
+
+def _bands(x, mask, mode, partition=False, dc_bits=0):
     """x: f32 [n, N, N] -> mode 0: Re IDFT2(mask_b * DFT2 x) [nb, n, N, N];  mode 1: (re, im) of mask_b * DFT2 x [nb, n, N, N, 2];
     mode 2: |.| in fftshift-ed coordinates."""
     n, N = x.shape[0], x.shape[1]
     nb = mask.shape[0]
+    if mode == 0 and partition and nb >= 2 and N in (64, 128):
+        # the band masks partition the spectrum: the whole decomposition in one launch on the f32 MFMA (csrc/fw_heads.hip)
+        out = torch.empty((nb, n, N, N), dtype=torch.float32, device=x.device)
+        call('fw_dft2_decompose', x, mask, _dft_panels(N, x.device), out, n, N, nb, int(dc_bits))
+        return out
     fr = torch.empty((n, N, N), dtype=torch.float32, device=x.device)
     fi = torch.empty_like(fr)
     call('fw_dft2_fwd', x, fr, fi, n, N)
@@ -75,6 +92,7 @@ class FrequencyDecompose(nn.Module):
         assert size > 0 and size <= 1, 'invalid frequency band width(size=%s)' % (size)
         self._masks = {}
         self._partition = False
+        self._dc_bits = 0
         if self.type in ['frequency_decompose', 'frequency_decompose_1']:
             if h != w or h & (h - 1) or not 8 <= h <= 256:
                 raise NotImplementedError('HIP band decomposition handles square power-of-two maps, 8 <= N <= 256')
@@ -85,7 +103,9 @@ class FrequencyDecompose(nn.Module):
         if key not in self._masks:
             m = torch.stack(lfs.band_masks_shifted(self.type, self.size, self.h, self.w)).float()
             self._partition = bool((m.sum(0) == 1).all())                                        # every frequency in exactly one band
-            self._masks[key] = torch.fft.ifftshift(m, dim=(-2, -1)).contiguous().to(device)     # host-built constant
+            un = torch.fft.ifftshift(m, dim=(-2, -1)).contiguous()
+            self._dc_bits = sum(1 << b for b in range(un.shape[0]) if float(un[b].sum()) == 1.0 and float(un[b, 0, 0]) == 1.0)
+            self._masks[key] = un.to(device)                                                     # host-built constant
         return self._masks[key]
 
     def forward(self, x):
@@ -106,7 +126,7 @@ class FrequencyDecompose(nn.Module):
         mode = 0 if self.inverse is True else 1 if self.inverse is False else 2
         assert self.inverse in (True, False, 'visual')
         xf = x.contiguous().float().reshape(n, N, N)
-        out = _BandsFn.apply(xf, mask, mode) if need_grad else _bands(xf.detach(), mask, mode, self._partition)
+        out = _BandsFn.apply(xf, mask, mode) if need_grad else _bands(xf.detach(), mask, mode, self._partition, self._dc_bits)
         out = out.reshape((nb, B, C, N, N, 2) if mode == 1 else (nb, B, C, N, N))
         if mode == 2:
             # the reference's fftshift has no dim argument: it also rolls the batch and channel axes (:32)

@@ -154,6 +154,12 @@ int fw_ema(int shadow_dtype, float* pk, const float* pq, void* shadow, long n, f
 int fw_dft2_fwd(const float* img, float* fr, float* fi, int nimg, int N, void* stream);
 int fw_dft2_bands(const float* fr, const float* fi, const float* mask_unshifted, float* out, int nimg, int N, int nbands,
                   int mode, void* stream);
+/* The same decomposition in ONE launch on the f32 MFMA for band masks that partition the spectrum (the encoder's pre-processing,
+ * encoder_Uformer.py:964-966 / frequency_decompose.py:70-107), N = 64 or 128: out[b] = Re IDFT2(mask_b . DFT2(img)) for b < nbands - 1,
+ * out[nbands-1] = img - the others.  panels: f32 [3][N][N] = cos, sin, -sin of 2 pi u i / N; dc_bits: bit b set = band b is the DC bin
+ * alone (written as the image mean, no transform). */
+int fw_dft2_decompose(const float* img, const float* mask, const float* panels, float* out, int nimg, int N, int nbands, int dc_bits,
+                      void* stream);
 /* Last band of a decomposition whose masks sum to one: out[nbands-1] = img - sum of the first nbands-1 bands of out
  * ([nbands][nimg][N][N], filled by fw_dft2_bands called with nbands-1).  Saves one masked inverse transform per image. */
 int fw_band_residual(const float* img, float* out, int nimg, int N, int nbands, void* stream);

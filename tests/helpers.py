@@ -67,3 +67,14 @@ def kdiff_state(variant='all3'):
         if name.startswith('E.E.encoder_k.') and O.is_parameter_key(name):
             st[name] = O.seeded_tensor(name, tuple(shape))
     return st
+
+
+# golden model_all3_kdiff: gradient norms of the three 448 -> 65 536 head weights evaluated in FLOAT64 by the oracle (same graph, same
+# weights).  dW = sum_t dY[t]^T xn[t] with sum_t dY[t] = 0 (BatchNorm backward) and xn[t] almost equal for all tokens (name-seeded
+# weights): the sum is what survives a cancellation, and the reference's own f32 evaluation (torch CPU) is 0.24 .. 0.41 % away from
+# the f64 value.  tests/test_oracle_model.py re-derives these constants; the HIP f32 path (exact-f32 MFMA products) must match THEM.
+KDIFF_HEAD_WEIGHT_NORMS_F64 = {
+    'E.E.encoder_q.mlp_head.0.1.weight': 0.028330916389931654,
+    'E.E.encoder_q.mlp_head.1.1.weight': 0.03231436757293798,
+    'E.E.encoder_q.mlp_head.2.1.weight': 0.015436637595669512,
+}

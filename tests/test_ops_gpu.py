@@ -490,6 +490,16 @@ def test_dft_band_decomposition(N):
         call('fw_dft2_bands', fr, fi, mu, outp, 3, N, nb - 1, 0)
         call('fw_band_residual', x.to(DEV), outp, 3, N, nb)
         close(outp, ref, 2e-5, f'{kind} real bands, last by subtraction')
+        if N in (64, 128):                                          # the one-launch f32-MFMA form the model's encoder pre-processing takes
+            from net.utils.frequency_decompose import FrequencyDecompose, _dft_panels
+            dc = sum(1 << b for b in range(nb) if float(masks[b].sum()) == 1.0 and float(mu[b, 0, 0]) == 1.0)
+            assert dc == (1 if kind == 'frequency_decompose_1' else 0)
+            for bits in (dc, 0):                                     # with the DC band as the mean, and through the full transform
+                outm = torch.full((nb, 3, N, N), float('nan'), device=DEV)
+                call('fw_dft2_decompose', x.to(DEV), mu, _dft_panels(N, torch.device(DEV)), outm, 3, N, nb, bits)
+                close(outm, ref, 2e-5, f'{kind} one-launch MFMA decomposition (dc_bits {bits})')
+            mod = FrequencyDecompose(kind, size, N, N)
+            close(mod(x.view(1, 3, N, N).to(DEV))[:, 0], ref, 2e-5, f'{kind} through the module')
         out2 = torch.empty(nb, 3, N, N, 2, device=DEV)
         call('fw_dft2_bands', fr, fi, mu, out2, 3, N, nb, 1)
         ref2 = O.frequency_decompose(x.view(1, 3, N, N).double(), kind, size, N, N, False)[:, 0]

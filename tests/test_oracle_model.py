@@ -75,6 +75,25 @@ def test_train_step_with_order_one_contrastive_loss():
     close(st['E.E.queue'], g['queue_after'], 1e-5, 'queue')
 
 
+def test_kdiff_head_weight_norms_in_float64():
+    """The float64 evaluation of the kdiff graph: the three head-weight gradient norms the GPU test judges the HIP path against
+    (helpers.KDIFF_HEAD_WEIGHT_NORMS_F64), and the distance of the reference's f32 values from them (0.24 .. 0.41 %)."""
+    from helpers import KDIFF_HEAD_WEIGHT_NORMS_F64 as F64, kdiff_state
+    g = load('model_all3_kdiff')
+    st = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in kdiff_state().items()}
+    names = [str(n) for n in g['grad_names']]
+    for n in names:
+        st[n] = st[n].clone().requires_grad_(True)
+    clean, q, k = (t.double() for t in synth_batch(2, 128, 'model.'))
+    restored, logits, labels = O.airnet_forward(st, make_opt('all3'), q, k, True)
+    O.training_loss(make_opt('all3'), restored, logits, labels, clean)[0].backward()
+    for n, want in F64.items():
+        got = float(st[n].grad.norm())
+        assert abs(got - want) < 1e-9 * want, f'{n}: {got!r}'
+        ref = float(g['grad_norms'][names.index(n)])
+        assert 2e-3 < abs(ref - want) / want < 5e-3
+
+
 def test_256_eval_and_train_step():
     """Resolution-generic construction: the reference classes built with img_size=256 (golden model256_all3) -- the
     bottleneck is 16x16 there, so its odd blocks shift, the LFS heads average 256 tokens and the band split is a 256-point DFT."""

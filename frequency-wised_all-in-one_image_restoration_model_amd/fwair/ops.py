@@ -58,11 +58,11 @@ _flush_registered = [None]      # graph-task id of the backward pass whose end-o
 _keepalive = []          # pinned host tables referenced by captured HIP graphs (their memcpy nodes re-read them on replay)
 
 
-_HOST_WORDS = 16384      # int64 words per pinned table: room for ~1400 slabs
+_HOST_WORDS = 65536      # int64 words per pinned table: room for ~1400 slabs, or ~28 000 work items of a grouped weight-gradient launch
 _host_ring, _host_next, _host_reserved = [], [0], []
 
 
-def reserve_capture_tables(count=4):
+def reserve_capture_tables(count=6):
     """Pinned host memory cannot be allocated while a stream is being captured: the engine reserves the tables a capture
     will consume beforehand.  A captured table is never reused (the graph's memcpy node re-reads it at every replay)."""
     while len(_host_reserved) < count:
@@ -97,17 +97,15 @@ def slab_reduce(slab, nz, n, zstride, dst, dst2=None, off2=0, n2=0, defer=False)
     if not defer or not _in_backward():
         call('fw_slab_reduce', slab, nz, n, zstride, dst, 1, dst2, off2, n2 if dst2 is not None else 0)
         return
-    task = torch._C._current_graph_task_id()
-    if _flush_registered[0] != task:                       # a new backward pass (an earlier one may have died before its callback ran)
-        if _flush_registered[0] is not None and _pending:
-            _pending.clear()                               # partials of a pass that never finished: their gradients are void anyway
-        _flush_registered[0] = task
-        torch.autograd.Variable._execution_engine.queue_callback(flush_slabs)
+    _register_flush()
     _pending.append((slab, nz, n, zstride, dst, dst2, off2, n2 if dst2 is not None else 0))
 
 
 def flush_slabs():
+    """End-of-backward-pass callback: the grouped weight gradients first (they queue the slabs of their sliced reductions), then ONE
+    fold of every slab of the pass."""
     _flush_registered[0] = None
+    _flush_wgrads()
     if not _pending:
         return
     items = list(_pending)
@@ -147,9 +145,109 @@ def flush_slabs():
     # `items` (the slabs) die here: the allocator reuses them stream-ordered, i.e. after the kernel above
 
 
+# ---- grouped weight gradients: every dW = dY^T x of a backward pass in one launch (csrc/fw_gemm.hip: gemm_wgrad_group_kernel) --------
+_GROUP = int(_os.environ.get('FW_WGRAD_GROUP', '1'))                # 0: one launch per product (round-2 behaviour)
+_GROUP_CHUNK = int(_os.environ.get('FW_WGRAD_CHUNK', '4096'))       # tokens per work item: longer reductions are cut into slices (sweep on MI355X: 1024: 298.6, 2048: 307.5, 4096: 305.6-308.7, 8192: 302.3, 16384: 281.3 images/s)
+_GROUP_BIG_MIN = int(_os.environ.get('FW_WGRAD_BIG_MIN', '224'))  # smallest output side that takes the 256 x 256 tile form
+_pending_w = []          # (g, x, n, k, m, dw, db)
+
+
+def _register_flush():
+    task = torch._C._current_graph_task_id()
+    if _flush_registered[0] != task:                       # a new backward pass (an earlier one may have died before its callback ran)
+        if _flush_registered[0] is not None:
+            _pending.clear(); _pending_w.clear()           # work of a pass that never finished: its gradients are void anyway
+        _flush_registered[0] = task
+        torch.autograd.Variable._execution_engine.queue_callback(flush_slabs)
+
+
+def _groupable(g, x, n, k, m, dw, db):
+    return (_GROUP and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and m % 32 == 0 and g.stride(1) == 1 and x.stride(1) == 1
+            and g.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and n >= 8 and k % 4 == 0
+            and dw.dtype == torch.float32 and dw.stride(1) == 1 and dw.stride(0) % 4 == 0 and dw.data_ptr() % 16 == 0)
+
+
+def _flush_wgrads():
+    """Launch the queued weight gradients: ONE fw_wgrad_group over (problem, tile, slice) work items.  A product whose reduction is
+    longer than FW_WGRAD_CHUNK tokens is cut into slices that store partial tiles into a slab (folded with the other slabs of the
+    pass right after); everything else owns its whole reduction and adds straight into the gradient -- no slab at all."""
+    if not _pending_w:
+        return
+    work = list(_pending_w)
+    _pending_w.clear()
+    # outputs of at least _GROUP_BIG_MIN rows and columns run on 256 x 256 tiles (8 waves), the others on 128 x 128 (4 waves)
+    big = [w for w in work if min(w[2], w[3]) >= _GROUP_BIG_MIN]
+    small = [w for w in work if min(w[2], w[3]) < _GROUP_BIG_MIN]
+    if big:
+        _launch_group(big, 256)
+    if small:
+        _launch_group(small, 128)
+
+
+def _launch_group(work, tile=128):
+    dev = work[0][0].device
+    rows, units = [], []
+    for pi, (g, x, n, k, m, dw, db) in enumerate(work):
+        tm, tn = (n + tile - 1) // tile, (k + tile - 1) // tile
+        sk = max(1, -(-m // _GROUP_CHUNK))
+        kper = -(-(-(-m // sk)) // 32) * 32                   # tokens per slice, whole 32-token steps
+        sk = -(-m // kper)
+        if sk == 1:
+            rows.append((g.data_ptr(), x.data_ptr(), dw.data_ptr(), g.stride(0), x.stride(0), dw.stride(0), n, k, m, kper, 1,
+                         db.data_ptr() if db is not None else 0, 0, 0, 1, 0))
+        else:
+            nk = (n * k + 3) // 4 * 4
+            S = nk + (n + 3) // 4 * 4
+            slab = torch.empty((sk, S), dtype=torch.float32, device=dev)
+            rows.append((g.data_ptr(), x.data_ptr(), slab.data_ptr(), g.stride(0), x.stride(0), k, n, k, m, kper, sk,
+                         slab.data_ptr() + 4 * nk if db is not None else 0, S, S if db is not None else 0, 0, 0))
+            assert dw.is_contiguous() or dw.stride(0) == k
+            _pending.append((slab, sk, n * k, S, dw, db, nk, n if db is not None else 0))
+        for z in range(sk):
+            for bx in range(tm):                                 # unit = the tiles of one slice that share dY rows (same bx): one XCD's L2
+                units.append((min(kper, m - z * kper), pi, bx, tn, z))
+    # Workgroups are dealt round-robin to the 8 XCDs (block p runs on XCD p % 8, in block order).  Units are handed, longest first, to the
+    # XCD with the least work so far (every XCD then runs ITS list longest-first: a long tile started last would be the tail); lists are
+    # padded to one length with empty items (problem -1).
+    units.sort(key=lambda u: -u[0])
+    lists, load = [[] for _ in range(8)], [0] * 8
+    for ln, pi, bx, tn, z in units:
+        x = load.index(min(load))
+        load[x] += ln * tn
+        lists[x].extend((pi, bx, by, z) for by in range(tn))
+    depth = max(len(li) for li in lists)
+    total = depth * 8
+    items = [lists[p & 7][p >> 3] if (p >> 3) < len(lists[p & 7]) else (-1, 0, 0, 0) for p in range(total)]
+    nprob = len(rows)
+    words = nprob * 16 + total * 2                               # items: 4 int32 = 2 int64 words each
+    if words > _HOST_WORDS and len(work) > 1:                    # more work than one pinned table describes: two launches
+        del _pending[len(_pending) - sum(1 for r_ in rows if r_[10] > 1):]          # the slabs queued above are re-made by the halves
+        _launch_group(work[:len(work) // 2], tile); _launch_group(work[len(work) // 2:], tile)
+        return
+    host = _host_table(words)
+    host[:nprob * 16].view(nprob, 16).copy_(torch.tensor(rows, dtype=torch.int64))
+    it32 = torch.tensor(items, dtype=torch.int32)
+    host[nprob * 16:].view(torch.int32).view(total, 4).copy_(it32)
+    table = torch.empty(host.shape, dtype=torch.int64, device=dev)
+    table.copy_(host, non_blocking=True)
+    probs = torch.empty(nprob * lib().fw_wgrad_group_prob_bytes(), dtype=torch.uint8, device=dev)
+    call('fw_wgrad_group', table, probs, nprob, table[nprob * 16:], total, tile)
+    if not torch.cuda.is_current_stream_capturing():
+        for slot in _host_ring:
+            if slot[0].data_ptr() == host.data_ptr():
+                slot[1].record()
+    # `work` (the operands) dies here: the allocator reuses them stream-ordered, i.e. after the kernel above
+
+
 def wgrad(g, x, n, k, m, dw, db=None, defer=False):
-    """dw[n][k] += sum_m g[m][n] x[m][k];  db[n] += sum_m g[m][n].  Large reductions are split over K into a slab of
-    partial tiles (plain stores) that a slab reduce folds -- no same-address atomics."""
+    """dw[n][k] += sum_m g[m][n] x[m][k];  db[n] += sum_m g[m][n].  With defer (dw / db are persistent gradient buffers nobody reads
+    before the optimizer step) inside a backward pass the product is QUEUED and runs in the pass's grouped launch (_flush_wgrads).
+    Otherwise: large reductions are split over K into a slab of partial tiles (plain stores) that a slab reduce folds -- no
+    same-address atomics."""
+    if defer and _in_backward() and _groupable(g, x, n, k, m, dw, db):
+        _register_flush()
+        _pending_w.append((g, x, n, k, m, dw, db))
+        return
     sk = pick_splitk(n, k, m, g.dtype)
     if sk == 1:
         gemm(g, x, n, k, m, x_trans=True, w_trans=True, out=dw, accumulate=True, xsum=db)

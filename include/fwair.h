@@ -42,6 +42,16 @@ int fw_gemm_last_variant(void);
  * "unsigned short" written bf16, e.g. "gemm_ring_kernel<bf16,128,2,true>"); returns its length, -1 on a bad buffer. */
 int fw_gemm_last_kernel(char* buf, int n);
 
+/* Every weight gradient dW = dY^T x of a backward pass in ONE launch (bf16 operands, both token-major; f32 dW): the host queues the
+ * products nobody reads before the optimizer step and hands over a table.  tab: device int64 [nprob][16] = {dY, x, dW, ld(dY), ld(x),
+ * ld(dW), rows of dW, columns of dW, tokens, tokens per slice (multiple of 32), slices, db (f32, or 0), c_zstride, xsum_zstride,
+ * accumulate, 0};  probs: device scratch, nprob * fw_wgrad_group_prob_bytes() bytes;  items: device int32 [nitems][4] = {problem,
+ * row tile, column tile, slice} in units of `tile` = 128 (4-wave workgroups) or 256 (8 waves: half the operand bytes per FLOP).  One slice: the tile adds into dW; several: slice z stores its partial tile at
+ * dW + z * c_zstride (fold with fw_slab_reduce_multi).  Replaces nn.Linear's weight / bias gradients of decoder_Uformer.py:98-125,294,
+ * leff.py:100,114 and the encoder's, as fw_gemm(x_trans = w_trans = 1) does one product at a time. */
+int fw_wgrad_group_prob_bytes(void);
+int fw_wgrad_group(const void* tab, void* probs, int nprob, const void* items, int nitems, int tile, void* stream);
+
 /* split-K without atomics: slice z stores its partial tile at C + z*c_zstride (and xsum + z*xsum_zstride); this sums the slices */
 int fw_slab_reduce(const float* slab, int nz, long n, long zstride, float* dst, int accumulate, float* dst2, long off2, long n2,
                    void* stream);

@@ -143,6 +143,48 @@ def test_gemm_tn_dw(dtype, M, N, K, split):
     close(db - 1, dy.sum(0), 1e-4, 'wgrad bias')
 
 
+def test_wgrad_group_one_launch_for_a_whole_backward_pass():
+    """fwair.ops.wgrad(defer=True) inside a backward pass queues the product; the end-of-pass callback launches ALL of them at once
+    (gemm_wgrad_group_kernel): un-split deep-stage shapes that add straight into the gradient (on top of what is already there),
+    tall reductions cut into slices whose partial tiles go through the slab fold, bias gradients both ways, ragged tiles."""
+    from fwair import ops as OP
+    shapes = [(448, 1792, 4096), (1344, 448, 4096), (56, 224, 40000 - 40000 % 32), (28, 28, 98304), (200, 72, 8192 + 64), (896, 896, 1024),
+              (224, 672, 16384), (300, 260, 8192 + 32)]       # outputs >= 224 on both sides take the 256 x 256 tile kernel (the last: ragged, sliced)
+    data = []
+    for i, (n, k, m) in enumerate(shapes):
+        g = (rnd(m, n, seed=i) * 0.3).to(torch.bfloat16)
+        x = (rnd(m, k, seed=100 + i) * 0.3).to(torch.bfloat16)
+        dw0 = rnd(n, k, seed=200 + i)                          # the gradient buffer already holds something: the product ADDS
+        data.append((g, x, dw0))
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t * 1.0
+
+        @staticmethod
+        def backward(ctx, d):
+            for (g, x, dw0), (dwd, dbd, gd, xd) in zip(data, dev):
+                OP.wgrad(gd, xd, gd.shape[1], xd.shape[1], gd.shape[0], dwd, dbd, defer=True)
+            assert len(OP._pending_w) == len(data), 'the products must be queued, not launched one by one'
+            return d
+
+    def padded(t):                                             # rows 16-byte aligned (ld multiple of 8), as the model's activations are
+        ld = (t.shape[1] + 7) // 8 * 8
+        buf = torch.zeros(t.shape[0], ld, dtype=t.dtype, device=DEV)
+        buf[:, :t.shape[1]] = t.to(DEV)
+        return buf[:, :t.shape[1]]
+
+    dev = [(dw0.clone().to(DEV), torch.zeros(g.shape[1], device=DEV), padded(g), padded(x)) for g, x, dw0 in data]
+    t = torch.ones(1, device=DEV, requires_grad=True)
+    Fn.apply(t).sum().backward()
+    assert not OP._pending_w and not OP._pending
+    for (g, x, dw0), (dwd, dbd, _, _) in zip(data, dev):
+        ref = dw0.double() + g.double().t() @ x.double()
+        close(dwd, ref, 2e-3, f'dW {tuple(ref.shape)} over {g.shape[0]} tokens')
+        close(dbd, g.double().sum(0), 2e-3, 'db')
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('M,N,K', [(32768 + 45, 224, 56), (33000, 56, 28), (32800, 448, 112), (32768, 132, 224), (40000, 672, 224),
                                    (32790, 28, 112)])

@@ -62,9 +62,11 @@ _HOST_WORDS = 65536      # int64 words per pinned table: room for ~1400 slabs, o
 _host_ring, _host_next, _host_reserved = [], [0], []
 
 
-def reserve_capture_tables(count=6):
+def reserve_capture_tables(count=None):
     """Pinned host memory cannot be allocated while a stream is being captured: the engine reserves the tables a capture
     will consume beforehand.  A captured table is never reused (the graph's memcpy node re-reads it at every replay)."""
+    if count is None:                                      # one per grouped weight-gradient launch and per slab fold of a captured pass
+        count = 64 if int(_os.environ.get('FW_WGRAD_STREAM', '0')) else 6
     while len(_host_reserved) < count:
         _host_reserved.append(torch.empty((_HOST_WORDS,), dtype=torch.int64, pin_memory=True))
 
@@ -105,7 +107,18 @@ def flush_slabs():
     """End-of-backward-pass callback: the grouped weight gradients first (they queue the slabs of their sliced reductions), then ONE
     fold of every slab of the pass."""
     _flush_registered[0] = None
-    _flush_wgrads()
+    if _SIDE and _pending_w and _side_flush():
+        pass
+    else:
+        _flush_wgrads()
+    _fold_slabs()
+    if _side_keep:                                           # join: the optimizer step (next on this stream) reads the gradients
+        for dev, side in _side_streams.items():
+            torch.cuda.current_stream(dev).wait_stream(side)
+        _side_keep.clear()
+
+
+def _fold_slabs():
     if not _pending:
         return
     items = list(_pending)
@@ -239,6 +252,50 @@ def _launch_group(work, tile=128):
     # `work` (the operands) dies here: the allocator reuses them stream-ordered, i.e. after the kernel above
 
 
+# ---- the queued weight gradients on a SIDE stream, a batch at a time, while the backward chain goes on -------------------------------
+# Weight gradients are off the critical path of a backward pass (nothing reads them before the optimizer step).  With
+# FW_WGRAD_STREAM=1 every FW_WGRAD_BATCH queued products are launched as one group on a second HIP stream (forked from the compute
+# stream by an event, joined at the end of the pass -- inside a captured step these become fork / join edges of the graph); their
+# operands stay referenced until the join, so the allocator cannot hand them out while the side stream still reads them.
+_SIDE = int(_os.environ.get('FW_WGRAD_STREAM', '0'))
+_SIDE_BATCH = int(_os.environ.get('FW_WGRAD_BATCH', '24'))
+_side_streams = {}
+_side_keep = []
+
+
+def _side_stream(dev):
+    s = _side_streams.get(dev)
+    if s is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        try:
+            s = torch.cuda.Stream(device=dev, priority=int(_os.environ.get('FW_WGRAD_STREAM_PRIORITY', '0')))
+        except Exception:
+            s = torch.cuda.Stream(device=dev)
+        _side_streams[dev] = s
+    return s
+
+
+def _side_flush():
+    """Launch what is queued so far on the side stream (the operands were produced on the current stream: wait for it first)."""
+    side = _side_stream(_pending_w[0][0].device)
+    if side is None:
+        return False
+    side.wait_stream(torch.cuda.current_stream())
+    _side_keep.extend(_pending_w)                            # operands live until the join
+    n0 = len(_pending)
+    with torch.cuda.stream(side):
+        _flush_wgrads()
+        if len(_pending) > n0:                               # slabs of the sliced products of THIS batch: fold them on the side stream too
+            mine = _pending[n0:]
+            del _pending[n0:]
+            keep = list(_pending)
+            _pending[:] = mine
+            _fold_slabs()
+            _pending[:] = keep
+    return True
+
+
 def wgrad(g, x, n, k, m, dw, db=None, defer=False):
     """dw[n][k] += sum_m g[m][n] x[m][k];  db[n] += sum_m g[m][n].  With defer (dw / db are persistent gradient buffers nobody reads
     before the optimizer step) inside a backward pass the product is QUEUED and runs in the pass's grouped launch (_flush_wgrads).
@@ -247,6 +304,8 @@ def wgrad(g, x, n, k, m, dw, db=None, defer=False):
     if defer and _in_backward() and _groupable(g, x, n, k, m, dw, db):
         _register_flush()
         _pending_w.append((g, x, n, k, m, dw, db))
+        if _SIDE and len(_pending_w) >= _SIDE_BATCH:
+            _side_flush()
         return
     sk = pick_splitk(n, k, m, g.dtype)
     if sk == 1:

@@ -44,21 +44,50 @@ def q(t, dtype):
     return t.to(dtype).float()
 
 
+# bf16 limits are MEASURED values, not guesses: tests/golden/bf16_measured.json holds, per check, the error this code showed on MI355X
+# (recorded with FW_RECORD_BF16=<path> python -m pytest tests/test_convnets_gpu.py -m gpu); a run must stay within TWICE its recorded
+# value (floor 0.02).  A check that has no record gets the plain limit 0.05 (relative Frobenius error) / 0.1 (gradient-norm deviation).
+import json as _json
+import os as _os
+
+_MEASURED_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), 'golden', 'bf16_measured.json')
+try:
+    with open(_MEASURED_PATH) as _f:
+        _MEASURED = _json.load(_f)
+except OSError:
+    _MEASURED = {}
+_RECORD = {}
+
+
+def _context():
+    return _os.environ.get('PYTEST_CURRENT_TEST', '').split('::')[-1].split(' ')[0]
+
+
+def bf16_limit(what, err, default):
+    """Limit of one bf16 check = 2 x its recorded measurement (floor 0.02), or `default` without a record; records when asked to."""
+    key = _context() + '|' + what
+    if _os.environ.get('FW_RECORD_BF16'):
+        _RECORD[key] = max(float(err), _RECORD.get(key, 0.0))
+        with open(_os.environ['FW_RECORD_BF16'], 'w') as f:
+            _json.dump(_RECORD, f, indent=0, sort_keys=True)
+        return float('inf')
+    if key in _MEASURED:
+        return max(2.0 * _MEASURED[key], 0.02)
+    return default
+
+
 def gclose(a, b, dt, tol32, what):
     """Gradient check.  f32: max-abs error relative to the reference's max (helpers.close).  bf16: every map between the
     convolutions and the batch normalisations is STORED in bf16 (8 significant bits) and BatchNorm divides by the batch deviation,
-    so single elements of a gradient (and whole gradients that are small by cancellation, e.g. of a BatchNorm weight) can be off
-    by 0.1-0.3 of the maximum while the tensor as a whole agrees: relative Frobenius error below 0.3 (see below)."""
+    so single elements of a gradient can be off by a large fraction of the maximum while the tensor as a whole agrees: relative
+    Frobenius error against twice the value measured for this very tensor (bf16_limit)."""
     if dt == 'fp32':
         return close(a, b, tol32, what)
     a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
     assert a.shape == b.shape and torch.isfinite(a).all(), what
     err = float((a - b).norm() / b.norm().clamp_min(1e-30))
-    # measured: 0.02-0.08 for most tensors, up to 0.21 for the gradients of the FIRST block (E.0.*: BatchNorm weight / bias and the
-    # shortcut convolution), which carry the rounding of the whole bf16 backward chain through five batch normalisations of a
-    # 2-image batch; the f32 run of the same code agrees to 2e-4, so the limit here only has to catch a wrong formula (error ~1)
-    lim = 0.3
-    assert err < lim, f'{what}: relative L2 error {err:.3e} >= {lim}'
+    lim = bf16_limit(what, err, 0.05)
+    assert err < lim, f'{what}: relative L2 error {err:.3e} >= {lim:.3e}'
     return err
 
 
@@ -222,7 +251,7 @@ def test_resnet_encoder_vs_reference(dt):
     norms = torch.tensor([params[n].grad.norm().item() for n in names], dtype=torch.float64)
     rel = (norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(float(g['grad_norms'].max()) * 1e-6)
     print(f'ResNet encoder {dt}: grad-norm deviation max {rel.max():.2e} median {rel.median():.2e}')
-    assert rel.max() < (1e-3 if dt == 'fp32' else 0.2) and rel.median() < (1e-4 if dt == 'fp32' else 3e-2)
+    assert rel.max() < (1e-3 if dt == 'fp32' else bf16_limit('grad-norm max', float(rel.max()), 0.1)) and rel.median() < (1e-4 if dt == 'fp32' else bf16_limit('grad-norm median', float(rel.median()), 0.03))
     for k, v in g.items():
         if k.startswith('g.'):
             gclose(params[k[2:]].grad, v, dt, t2, k)
@@ -255,7 +284,7 @@ def test_vit_encoder_vs_reference(dt):
     norms = torch.tensor([params[n].grad.norm().item() for n in names], dtype=torch.float64)
     rel = (norms - g['grad_norms']).abs() / g['grad_norms'].clamp_min(float(g['grad_norms'].max()) * 1e-6)
     print(f'ViT encoder {dt}: grad-norm deviation max {rel.max():.2e} median {rel.median():.2e}')
-    assert rel.max() < (2e-3 if dt == 'fp32' else 0.3) and rel.median() < (1e-4 if dt == 'fp32' else 5e-2)
+    assert rel.max() < (2e-3 if dt == 'fp32' else bf16_limit('grad-norm max', float(rel.max()), 0.1)) and rel.median() < (1e-4 if dt == 'fp32' else bf16_limit('grad-norm median', float(rel.median()), 0.03))
     for k, v in g.items():
         if k.startswith('g.'):
             close(params[k[2:]].grad, v, t2, k)
@@ -370,7 +399,7 @@ def test_resnet_dgrn_model_vs_oracle(dt):
     mine = torch.tensor([float(params[n].grad.norm()) for n in names], dtype=torch.float64)
     rel = (mine - gn).abs() / gn.clamp_min(float(gn.max()) * 1e-6)
     print(f'ResNet + DGRN {dt}: grad-norm deviation max {rel.max():.2e} median {rel.median():.2e} ({names[int(rel.argmax())]})')
-    assert rel.median() < (1e-4 if dt == 'fp32' else 5e-2) and rel.max() < (5e-3 if dt == 'fp32' else 1.0)
+    assert rel.median() < (1e-4 if dt == 'fp32' else bf16_limit('grad-norm median', float(rel.median()), 0.03)) and rel.max() < (5e-3 if dt == 'fp32' else bf16_limit('grad-norm max', float(rel.max()), 0.1))
     for n in ('R.R.tail.0.weight', 'R.R.head.0.weight', 'R.R.body.2.body.3.dgm1.dcn.weight', 'R.R.body.0.body.0.dgm2.dcn.conv_offset_mask.weight',
               'R.R.body.4.body.1.dgm1.sft.conv_gamma.0.weight', 'R.R.body.1.body.5.bias', 'E.E.encoder_q.E_pre.backbone.0.weight',
               'E.E.encoder_q.E.1.backbone.4.weight', 'E.E.encoder_q.mlp.2.weight'):

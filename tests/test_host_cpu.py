@@ -66,9 +66,13 @@ def test_unsupported_configurations_fail_loudly():
     from net.model import AirNet
     with pytest.raises(NotImplementedError):
         AirNet(make_opt('all3', degradation_embedding_method=['residual']))        # the CLI default does not run in the reference either
-    with pytest.raises(NotImplementedError):                                        # the band re-weighting `lamb` of the ViT attention
+    with pytest.raises(NotImplementedError):                                        # ViT: N = (S/16)^2 keys per head must be 64 or 256
         AirNet(make_opt('all3', encoder_type='ViT', encoder_dim=3, out_channels=3, batch_wise_decompose=False,
-                        degradation_embedding_method=['None'], frequency_decompose_type='3_bands'))
+                        degradation_embedding_method=['None'], patch_size=64))
+    net = AirNet(make_opt('all3', encoder_type='ViT', encoder_dim=3, out_channels=3, batch_wise_decompose=False,
+                          degradation_embedding_method=['None'], frequency_decompose_type='3_bands'))
+    lamb = net.E.E.encoder_q.transformer.layers[0][0].fn.lamb                       # the band re-weighting of the ViT attention (encoder_ViT.py:55-63)
+    assert tuple(lamb.shape) == (3, 1, 12) and lamb.requires_grad           # [bands, 1 (not batch-wise), heads]
 
 
 @pytest.mark.parametrize('variant,kw', [

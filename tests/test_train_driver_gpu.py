@@ -32,8 +32,8 @@ def test_two_phase_training_and_resume(tmp_path):
     assert os.path.exists(out + 'options.log')
     res = open(out + 'results.log').read().splitlines()                                                # train.py:131-139
     assert res[0] == '2 Epochs Results:' and res[3] == '3 Epochs Results:' and len(res) == 6
-    m = re.fullmatch(r'denoising_bsd68_25: {8}PSNR/SSIM: (\d+\.\d{2})/nan', res[1])
-    assert m and 5 < float(m.group(1)) < 60, res[1]
+    m = re.fullmatch(r'denoising_bsd68_25: {8}PSNR/SSIM: (\d+\.\d{2})/(\d\.\d{4})', res[1])           # val_utils.py:50-66: both metrics
+    assert m and 5 < float(m.group(1)) < 60 and 0 < float(m.group(2)) < 1, res[1]
     assert res[2].startswith('deraining: ' + ' ' * 16 + 'PSNR/SSIM: ')
     for e in (2, 3):
         assert os.path.exists(out + f'ckpt/epoch_{e}.pth') and os.path.exists(out + f'ckpt/epoch_{e}.opt.pth')

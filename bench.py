@@ -84,12 +84,38 @@ def gemm_profile(engine, batch, reps=8):
         rec.append(((M, N, K), tuple(sorted(tens.items())), scal))
         return r
 
+    # the weight gradients of a backward pass do not come through ops.gemm: they are queued and run as ONE grouped launch per tile
+    # form (ops._launch_group -> fw_wgrad_group).  Those launches last milliseconds, so HIP events around the launch call (ops._group_fire: the
+    # host-side list building stays outside) inside eager steps time them (mean of 3 steps); their FLOPs / bytes are the sums over the queued products.
+    grp, cur, orig_lg, orig_fire = [], [], ops._launch_group, ops._group_fire
+
+    def lg_hook(work, tile=128):
+        cur.append([(n, k, m, g.element_size(), dw.element_size(), db is not None) for (g, x, n, k, m, dw, db) in work])
+        try:
+            orig_lg(work, tile)                          # a table overflow re-enters with halves: each half is its own launch and row
+        finally:
+            cur.pop()
+
+    def fire_hook(table, probs, nprob, total, tile):     # the launch alone: the host-side list building stays outside the events
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_fire(table, probs, nprob, total, tile)
+        e1.record()
+        grp.append((tile, cur[-1], e0, e1))
+
     ops.gemm = hook
     try:
         engine.step_eager(*batch)
         torch.cuda.synchronize()
+        ops.gemm = orig
+        ops._launch_group, ops._group_fire = lg_hook, fire_hook
+        GROUP_STEPS = 3
+        for _ in range(GROUP_STEPS):
+            engine.step_eager(*batch)
+        torch.cuda.synchronize()
     finally:
         ops.gemm = orig
+        ops._launch_group, ops._group_fire = orig_lg, orig_fire
     counts = {}
     for sig in rec:
         counts[sig] = counts.get(sig, 0) + 1
@@ -162,6 +188,25 @@ def gemm_profile(engine, batch, reps=8):
                          [k for k, _ in tens if k not in ('x', 'w', 'out')] + [str(kw['out'].dtype).replace('torch.', 'out_')])
         out.append((variant, (M, N, K, sk, flags), cnt, 2.0 * M * N * K, float(by), dt, float(over)))
         del g, sets, kw, x, w
+    chunk = ops._GROUP_CHUNK
+    by_tile = {}
+    for tile, probs, e0, e1 in grp:
+        by_tile.setdefault(tile, []).append((probs, e0.elapsed_time(e1) * 1e-3))
+    for tile, runs in by_tile.items():
+        per_step = len(runs) // GROUP_STEPS                   # launches of this tile form in one step
+        dt = sum(t for _, t in runs) / len(runs)
+        fl = by = over = 0.0
+        for probs, _ in runs[:per_step]:
+            for n, k, m, sz, osz, has_b in probs:
+                fl += 2.0 * n * k * m
+                by += (n * m + k * m) * sz + n * k * osz + (n * osz if has_b else 0)
+                sk = max(1, -(-m // chunk))
+                over += n * k * osz * ((2 * sk - 1) if sk > 1 else 1)     # sliced: slab writes + fold reads; whole: the RMW read of dW
+        nprob = sum(len(p) for p, _ in runs[:per_step])
+        kern = 'gemm_wgrad_group_big_kernel' if tile == 256 else 'gemm_wgrad_group_kernel'
+        # one row per tile form: "launch" = the mean of its launches of a step; FLOPs / bytes per launch likewise
+        out.append((('bf16', kern), (nprob, 0, 0, 1, f'grouped dW=dY^T x: {nprob} products in {per_step} launch(es) of {tile}x{tile} tiles'),
+                    per_step, fl / per_step, by / per_step, dt, over / per_step))
     agg = {}
     for variant, shape, cnt, fl, by, dt, over in out:
         d = agg.setdefault(variant, [0.0, 0.0, 0, 0.0, 0.0, 0.0])
@@ -176,10 +221,10 @@ def gemm_profile(engine, batch, reps=8):
                 roof = max(fl / PEAK_FOR[v[0]], by / PEAK_HBM) * 1e6
                 f.write(f'{v[0]},"{v[1]}",{sh[0]},{sh[1]},{sh[2]},{sh[3]},{cnt},{dt * 1e6:.1f},'
                         f'{dt * cnt * 1e3:.3f},{fl / dt / 1e12:.1f},{by / dt / 1e9:.0f},{roof:.1f},{sh[4]}\n')
-    return agg, len(rec)
+    return agg, len(rec) + len(grp) // GROUP_STEPS
 
 
-PMC_FILE = 'r02_pmc_traffic.json'
+PMC_FILE = 'r03_pmc_traffic.json'
 
 
 def pmc_traffic(kernel):

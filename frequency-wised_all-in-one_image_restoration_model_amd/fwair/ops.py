@@ -66,7 +66,7 @@ def reserve_capture_tables(count=None):
     """Pinned host memory cannot be allocated while a stream is being captured: the engine reserves the tables a capture
     will consume beforehand.  A captured table is never reused (the graph's memcpy node re-reads it at every replay)."""
     if count is None:                                      # one per grouped weight-gradient launch and per slab fold of a captured pass
-        count = 64 if int(_os.environ.get('FW_WGRAD_STREAM', '0')) else 6
+        count = 6
     while len(_host_reserved) < count:
         _host_reserved.append(torch.empty((_HOST_WORDS,), dtype=torch.int64, pin_memory=True))
 
@@ -107,15 +107,8 @@ def flush_slabs():
     """End-of-backward-pass callback: the grouped weight gradients first (they queue the slabs of their sliced reductions), then ONE
     fold of every slab of the pass."""
     _flush_registered[0] = None
-    if _SIDE and _pending_w and _side_flush():
-        pass
-    else:
-        _flush_wgrads()
+    _flush_wgrads()
     _fold_slabs()
-    if _side_keep:                                           # join: the optimizer step (next on this stream) reads the gradients
-        for dev, side in _side_streams.items():
-            torch.cuda.current_stream(dev).wait_stream(side)
-        _side_keep.clear()
 
 
 def _fold_slabs():
@@ -197,6 +190,11 @@ def _flush_wgrads():
         _launch_group(small, 128)
 
 
+def _group_fire(table, probs, nprob, total, tile):
+    """The launch itself, apart from the host-side list building (bench.py times exactly this call)."""
+    call('fw_wgrad_group', table, probs, nprob, table[nprob * 16:], total, tile)
+
+
 def _launch_group(work, tile=128):
     dev = work[0][0].device
     rows, units = [], []
@@ -244,56 +242,12 @@ def _launch_group(work, tile=128):
     table = torch.empty(host.shape, dtype=torch.int64, device=dev)
     table.copy_(host, non_blocking=True)
     probs = torch.empty(nprob * lib().fw_wgrad_group_prob_bytes(), dtype=torch.uint8, device=dev)
-    call('fw_wgrad_group', table, probs, nprob, table[nprob * 16:], total, tile)
+    _group_fire(table, probs, nprob, total, tile)
     if not torch.cuda.is_current_stream_capturing():
         for slot in _host_ring:
             if slot[0].data_ptr() == host.data_ptr():
                 slot[1].record()
     # `work` (the operands) dies here: the allocator reuses them stream-ordered, i.e. after the kernel above
-
-
-# ---- the queued weight gradients on a SIDE stream, a batch at a time, while the backward chain goes on -------------------------------
-# Weight gradients are off the critical path of a backward pass (nothing reads them before the optimizer step).  With
-# FW_WGRAD_STREAM=1 every FW_WGRAD_BATCH queued products are launched as one group on a second HIP stream (forked from the compute
-# stream by an event, joined at the end of the pass -- inside a captured step these become fork / join edges of the graph); their
-# operands stay referenced until the join, so the allocator cannot hand them out while the side stream still reads them.
-_SIDE = int(_os.environ.get('FW_WGRAD_STREAM', '0'))
-_SIDE_BATCH = int(_os.environ.get('FW_WGRAD_BATCH', '24'))
-_side_streams = {}
-_side_keep = []
-
-
-def _side_stream(dev):
-    s = _side_streams.get(dev)
-    if s is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        try:
-            s = torch.cuda.Stream(device=dev, priority=int(_os.environ.get('FW_WGRAD_STREAM_PRIORITY', '0')))
-        except Exception:
-            s = torch.cuda.Stream(device=dev)
-        _side_streams[dev] = s
-    return s
-
-
-def _side_flush():
-    """Launch what is queued so far on the side stream (the operands were produced on the current stream: wait for it first)."""
-    side = _side_stream(_pending_w[0][0].device)
-    if side is None:
-        return False
-    side.wait_stream(torch.cuda.current_stream())
-    _side_keep.extend(_pending_w)                            # operands live until the join
-    n0 = len(_pending)
-    with torch.cuda.stream(side):
-        _flush_wgrads()
-        if len(_pending) > n0:                               # slabs of the sliced products of THIS batch: fold them on the side stream too
-            mine = _pending[n0:]
-            del _pending[n0:]
-            keep = list(_pending)
-            _pending[:] = mine
-            _fold_slabs()
-            _pending[:] = keep
-    return True
 
 
 def wgrad(g, x, n, k, m, dw, db=None, defer=False):
@@ -304,8 +258,6 @@ def wgrad(g, x, n, k, m, dw, db=None, defer=False):
     if defer and _in_backward() and _groupable(g, x, n, k, m, dw, db):
         _register_flush()
         _pending_w.append((g, x, n, k, m, dw, db))
-        if _SIDE and len(_pending_w) >= _SIDE_BATCH:
-            _side_flush()
         return
     sk = pick_splitk(n, k, m, g.dtype)
     if sk == 1:

@@ -455,6 +455,180 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
     }
 }
 
+// Whole backward of the depthwise 3x3 in ONE pass over its operands (dh2 and h1 read once, dh1 written once; the two-kernel form read
+// dh2 and h1 twice -- 5 tensor passes instead of 3 -- and evaluated the 30-tap gather twice).  Both gradients gather the SAME
+// neighbourhood of dh2 around an input pixel p:
+//     dh1[p]      = GELU'(h1[p]) * sum_tap w[tap] dh2[p - tap + 1]
+//     dw[tap]    += GELU(h1[p]) * dh2[p - tap + 1]            dbias += dh2[p]
+// so the data-gradient tile kernel's stencil loop carries one more FMA per tap.  A workgroup is PERSISTENT over NT vertically
+// consecutive 8 x 16 x 64-channel tiles: its 10 x 4 weight-gradient partials stay in registers across tiles and end in one fold
+// (wave shuffles, LDS, then 640 atomics per workgroup instead of per tile), and the next tile's halo pieces / h1 vectors are in
+// flight (registers) while the current tile is computed from LDS -- the one-shot tile kernel had no overlap inside a workgroup.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void dwconv_bwd_fused_kernel(const T* __restrict__ dh2, long ldg, const T* __restrict__ h1, const float* __restrict__ w,
+                                                               T* __restrict__ dh1, long ldo, float* __restrict__ dw, float* __restrict__ dbias,
+                                                               int B, int H, int W, int C, int NT) {
+    constexpr int SZ = TT<T>::SZ, E16 = TT<T>::E16;
+    constexpr int PXB = DT_CB * SZ, ROWB = (DT_TX + 2) * PXB + 128, CHUNKS = PXB / 16;
+    constexpr int NPIECE = (DT_TY + 2) * (DT_TX + 2) * CHUNKS, NI = (NPIECE + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int ncb = (C + DT_CB - 1) / DT_CB, ntx = (W + DT_TX - 1) / DT_TX, nty = H / DT_TY;
+    const int ncol = ncb * ntx;
+    const long nrow = (long)B * nty, nchunk = (nrow + NT - 1) / NT;
+    long bid = blockIdx.x;                                   // contiguous eighth of the block order per XCD: horizontal neighbours share halo columns in that L2
+    if ((gridDim.x & 7) == 0) bid = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int col = (int)(bid % ncol);
+    const long chunk = bid / ncol;
+    if (chunk >= nchunk) return;
+    const int cb = col % ncb, tx = col / ncb;
+    const long s0 = chunk * NT, s1 = s0 + NT < nrow ? s0 + NT : nrow;
+    const int x0 = tx * DT_TX, c0b = cb * DT_CB;
+    // ---- tile-independent part of the halo pieces (32-bit offsets: a tile row base is uniform, the rest of an address fits an int) ----
+    int ppack[NI], pxo[NI];                                  // LDS offset | halo row << 24;  element offset of (clamped x, channel chunk)
+    unsigned pokm = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int ch = idx % CHUNKS, px = (idx / CHUNKS) % (DT_TX + 2), row = (idx / (CHUNKS * (DT_TX + 2))) % (DT_TY + 2);
+        int xx = x0 + px - 1, cc = c0b + ch * E16;
+        if (idx < NPIECE && xx >= 0 && xx < W && cc + E16 <= C) pokm |= 1u << i;
+        xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx); cc = cc + E16 <= C ? cc : 0;
+        pxo[i] = xx * (int)ldg + cc; ppack[i] = (row * ROWB + px * PXB + ch * 16) | (row << 24);
+    }
+    const int cv = threadIdx.x & 15, ry = (threadIdx.x >> 4) & 7, sxl = threadIdx.x >> 7;
+    const int c0 = c0b + cv * 4;
+    const bool c_ok = c0 + 4 <= C;
+    const int cw = c_ok ? c0 : 0;
+    const int ox0 = x0 + sxl * 8;
+    // LDS beyond the halo tile: the 9 x 64 flipped weights of this channel block (read back as one float4 per tap: 36 registers less
+    // than holding them), and the weight-gradient partials, one private slot per (value, thread) -- [40][256] floats, conflict-free.
+    constexpr int TILEB = (DT_TY + 2) * ROWB;
+    float* wl = reinterpret_cast<float*>(dsm + TILEB);                  // [9][64]
+    float* part = wl + 9 * DT_CB;                                       // [40][256]
+    for (int i = threadIdx.x; i < 9 * DT_CB; i += 256) {
+        const int k = i / DT_CB, c = c0b + (i % DT_CB);
+        wl[i] = c < C ? w[(8 - k) * C + c] : 0.f;                       // flipped taps, as in the data-gradient kernels
+    }
+#pragma unroll
+    for (int j = 0; j < 40; ++j) part[j * 256 + threadIdx.x] = 0.f;
+    float gb[4] = {0.f, 0.f, 0.f, 0.f};                                 // bias-gradient partial
+    uint4 r[NI];
+    Raw4<T> pre[8];
+    const int rowelems = W * (int)ldg;                        // elements per image row (< 2^31 / H: checked by the host)
+    auto issue_halo = [&](long s) {                           // the dh2 halo pieces of tile row s (branch-free: clamped coordinates)
+        const T* base = dh2 + (s / nty) * H * (long)rowelems;
+        const int y0 = (int)(s % nty) * DT_TY;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int yy = y0 + (ppack[i] >> 24) - 1;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            r[i] = *reinterpret_cast<const uint4*>(base + (yy * rowelems + pxo[i]));
+        }
+    };
+    auto issue_pre = [&](long s) {                            // this thread's 8 h1 vectors of tile row s
+        const T* base = h1 + (s / nty) * H * (long)rowelems;
+        const int yoff = ((int)(s % nty) * DT_TY + ry) * rowelems + cw;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int xx = ox0 + o < W ? ox0 + o : W - 1;
+            pre[o].load(base + (yoff + xx * (int)ldg));
+        }
+    };
+    issue_halo(s0);
+    issue_pre(s0);
+    for (long s = s0; s < s1; ++s) {
+        const long b = s / nty;
+        const int y0 = (int)(s % nty) * DT_TY;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (threadIdx.x + i * 256 >= NPIECE) continue;
+            const int yy = y0 + (ppack[i] >> 24) - 1;
+            *reinterpret_cast<uint4*>(dsm + (ppack[i] & 0xffffff)) = (((pokm >> i) & 1) && yy >= 0 && yy < H) ? r[i] : make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        if (s + 1 < s1) issue_halo(s + 1);                    // in flight while this tile is computed
+        float g[8][4], acc[8][4];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float hc[4];
+            pre[o].unpack(hc);
+            const bool in = ox0 + o < W;                     // a strip pixel beyond the image edge contributes nothing
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g[o][e] = in ? gelu_t<T>(hc[e]) : 0.f; acc[o][e] = 0.f; }
+        }
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+            const char* rowp = dsm + (ry + ky) * ROWB + (sxl * 8) * PXB + cv * 4 * SZ;
+            f32x4 wk[3];
+            float gk[3][4];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                wk[kx] = *reinterpret_cast<const f32x4*>(wl + (ky * 3 + kx) * DT_CB + cv * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gk[kx][e] = 0.f;
+            }
+            const float bsel = ky == 1 ? 1.f : 0.f;             // the centre row carries the bias gradient
+#pragma unroll
+            for (int cx = 0; cx < 10; ++cx) {
+                Raw4<T> q;
+                q.lds(rowp + cx * PXB);
+                float f[4];
+                q.unpack(f);
+                if (cx >= 1 && cx <= 8) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gb[e] += bsel * f[e];
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int o = cx - kx;                   // tile pixel cx is x = ox0 + cx - 1
+                    if (o >= 0 && o < 8) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[o][e] += f[e] * wk[kx][e];
+                            gk[kx][e] += f[e] * g[o][e];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[((ky * 3 + kx) * 4 + e) * 256 + threadIdx.x] += gk[kx][e];
+        }
+        T* orow = dh1 + ((b * H + y0 + ry) * W + ox0) * ldo + c0;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float hc[4];
+            pre[o].unpack(hc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[o][e] *= gelu_grad_t<T>(hc[e]);
+            if (c_ok && ox0 + o < W) stvec4<T>(orow + (long)o * ldo, acc[o]);
+        }
+        if (s + 1 < s1) issue_pre(s + 1);                     // h1 of the next tile: in flight across the barrier and the LDS staging
+        __syncthreads();                                      // every wave is done with the tile before the next one overwrites it
+    }
+    // ---- fold the partials of the 16 threads that share a channel vector: ry bits inside the wave, then the 4 waves through LDS ----
+    float* red = reinterpret_cast<float*>(dsm);               // the halo tile is free now (the loop ended in a barrier)
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 40; ++j) {
+        float v = j < 36 ? part[j * 256 + threadIdx.x] : gb[j - 36];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if ((threadIdx.x & 63) < 16) red[(wave * 16 + cv) * 40 + j] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * 40; i += 256) {
+        const int cvv = i / 40, j = i % 40, k = j >> 2, e = j & 3;
+        const float sum = red[cvv * 40 + j] + red[(16 + cvv) * 40 + j] + red[(32 + cvv) * 40 + j] + red[(48 + cvv) * 40 + j];
+        const int c = c0b + cvv * 4 + e;
+        if (c < C) {
+            if (k < 9) atomicAdd(dw + (long)c * 9 + (8 - k), sum);                    // gw[k] pairs with the flipped tap 8 - k
+            else atomicAdd(dbias + c, sum);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k4 s2 p1 convolution as GEMM: im2col (f32 stream -> T, K order (ky,kx,ci)) and its adjoint
 // ------------------------------------------------------------------------------------------------
@@ -1029,6 +1203,27 @@ extern "C" int fw_dwconv_bwd(int dtype, const void* dh2, long ldg, const void* g
     const long nsg = (nst + (long)NSTRIP * WG_SL - 1) / ((long)NSTRIP * WG_SL);
     const dim3 gridw((unsigned)(nsg * nvg));
     const bool tiled = dw_tiled() && H % DT_TY == 0 && (long)B * H * W * C >= dw_tiled_min();
+    static const int fused = getenv("FW_DWCONV_FUSED_BWD") ? atoi(getenv("FW_DWCONV_FUSED_BWD")) : 1;
+    if (tiled && fused && !g1 && (long)H * W * ldg < (1L << 31)) {                    // one pass: data gradient + weight / bias gradient (dwconv_bwd_fused_kernel)
+        static const long want = getenv("FW_DWCONV_FUSED_WGS") ? atol(getenv("FW_DWCONV_FUSED_WGS")) : 1024;
+        const long ncol = (long)((C + DT_CB - 1) / DT_CB) * ((W + DT_TX - 1) / DT_TX), nrow = (long)B * (H / DT_TY);
+        long NT = ncol * nrow / want;               // tiles a workgroup walks: as many as still leave ~`want` workgroups
+        NT = NT < 1 ? 1 : (NT > 32 ? 32 : NT);
+        long nb = ncol * ((nrow + NT - 1) / NT);
+        nb = (nb + 7) / 8 * 8;
+        const size_t esz = dtype == FW_DT_BF16 ? 2 : 4;
+        const size_t lds = (size_t)(DT_TY + 2) * ((DT_TX + 2) * DT_CB * esz + 128) + (9 * DT_CB + 40 * 256) * sizeof(float);   // halo tile + weights + partials
+        if (dtype == FW_DT_BF16) {
+            FW_SET_LDS_ONCE((dwconv_bwd_fused_kernel<bf16raw>), lds);
+            hipLaunchKernelGGL((dwconv_bwd_fused_kernel<bf16raw>), dim3((unsigned)nb), dim3(256), lds, ST, (const bf16raw*)dh2, ldg, (const bf16raw*)h1, w,
+                               (bf16raw*)dh1, ldo, dw, dbias, B, H, W, C, (int)NT);
+        } else {
+            FW_SET_LDS_ONCE((dwconv_bwd_fused_kernel<float>), lds);
+            hipLaunchKernelGGL((dwconv_bwd_fused_kernel<float>), dim3((unsigned)nb), dim3(256), lds, ST, (const float*)dh2, ldg, (const float*)h1, w,
+                               (float*)dh1, ldo, dw, dbias, B, H, W, C, (int)NT);
+        }
+        FW_LAUNCH_RET();
+    }
     if (tiled) {
         const int rc = dtype == FW_DT_BF16
             ? dwconv_tile_launch<bf16raw, 1>((const bf16raw*)dh2, ldg, w, (const float*)nullptr, (const bf16raw*)h1, (bf16raw*)dh1, (bf16raw*)nullptr, ldo, B, H, W, C, ST)

@@ -757,12 +757,16 @@ def test_attention_encoder_timed_shape(dtype, mode):
     close(dbias, tables.grad, tol * 2, 'dbias tables summed over 4096 windows')
 
 
+@pytest.mark.parametrize('shape', [(16, 128, 128, 448), (4, 136, 120, 168), (48, 16, 16, 896)])
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_dwconv_tiled_kernel_timed_shape(dtype):
-    """LeFF depthwise 3x3 of decoderlayer_0 in the timed step: B = 16, 128x128, hidden 448 -> 117 M elements >= the 80 M threshold
-    of fw_dwconv_fwd / fw_dwconv_bwd, so dwconv_tile_kernel<*, 0> (forward + GELU twin) and <*, 1> (data gradient) run."""
-    B, H, W, C = 16, 128, 128, 448
-    assert B * H * W * C >= 80_000_000
+def test_dwconv_tiled_kernel_timed_shape(dtype, shape):
+    """LeFF depthwise 3x3 of decoderlayer_0 in the timed step: B = 16, 128x128, hidden 448 -> 117 M elements >= the 10 M threshold
+    of fw_dwconv_fwd / fw_dwconv_bwd, so dwconv_tile_kernel<*, 0> (forward + GELU twin) and dwconv_bwd_fused_kernel (data + weight +
+    bias gradient in one pass, persistent over vertically consecutive tiles) run.  Second shape: ragged everywhere -- W = 120 is no
+    multiple of the 16-pixel tile, C = 168 leaves a 40-channel last block, 4 x 17 tile rows do not divide by the tiles a workgroup
+    walks (workgroups cross image borders).  Third: the smallest tiled layer of the step (one tile per image column)."""
+    B, H, W, C = shape
+    assert B * H * W * C >= 10_000_000
     h1 = q(rnd(B * H * W, C), dtype).requires_grad_(True)
     w = (rnd(C, 1, 3, 3, seed=1) * 0.3).requires_grad_(True)
     b = (rnd(C, seed=2) * 0.1).requires_grad_(True)

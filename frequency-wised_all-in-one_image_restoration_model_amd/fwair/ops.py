@@ -155,6 +155,7 @@ def _fold_slabs():
 _GROUP = int(_os.environ.get('FW_WGRAD_GROUP', '1'))                # 0: one launch per product (round-2 behaviour)
 _GROUP_CHUNK = int(_os.environ.get('FW_WGRAD_CHUNK', '4096'))       # tokens per work item: longer reductions are cut into slices (sweep on MI355X: 1024: 298.6, 2048: 307.5, 4096: 305.6-308.7, 8192: 302.3, 16384: 281.3 images/s)
 _GROUP_BIG_MIN = int(_os.environ.get('FW_WGRAD_BIG_MIN', '224'))  # smallest output side that takes the 256 x 256 tile form
+_GROUP_UNIT_BX = int(_os.environ.get('FW_WGRAD_UNIT_BX', '1'))    # dY column blocks per work unit (see _launch_group)
 _pending_w = []          # (g, x, n, k, m, dw, db)
 
 
@@ -215,17 +216,19 @@ def _launch_group(work, tile=128):
             assert dw.is_contiguous() or dw.stride(0) == k
             _pending.append((slab, sk, n * k, S, dw, db, nk, n if db is not None else 0))
         for z in range(sk):
-            for bx in range(tm):                                 # unit = the tiles of one slice that share dY rows (same bx): one XCD's L2
-                units.append((min(kper, m - z * kper), pi, bx, tn, z))
+            # unit = a block of _GROUP_UNIT_BX x tn tiles of one slice, run back to back on ONE XCD: its tiles share dY column blocks
+            # (same bx) and x column blocks (same by) in that L2 -- HBM reads per unit ~ (u + tn) operand blocks for u * tn tiles
+            for bx in range(0, tm, _GROUP_UNIT_BX):
+                units.append((min(kper, m - z * kper), pi, bx, min(_GROUP_UNIT_BX, tm - bx), tn, z))
     # Workgroups are dealt round-robin to the 8 XCDs (block p runs on XCD p % 8, in block order).  Units are handed, longest first, to the
     # XCD with the least work so far (every XCD then runs ITS list longest-first: a long tile started last would be the tail); lists are
     # padded to one length with empty items (problem -1).
     units.sort(key=lambda u: -u[0])
     lists, load = [[] for _ in range(8)], [0] * 8
-    for ln, pi, bx, tn, z in units:
+    for ln, pi, bx, u, tn, z in units:
         x = load.index(min(load))
-        load[x] += ln * tn
-        lists[x].extend((pi, bx, by, z) for by in range(tn))
+        load[x] += ln * tn * u
+        lists[x].extend((pi, bx + i, by, z) for by in range(tn) for i in range(u))
     depth = max(len(li) for li in lists)
     total = depth * 8
     items = [lists[p & 7][p >> 3] if (p >> 3) < len(lists[p & 7]) else (-1, 0, 0, 0) for p in range(total)]

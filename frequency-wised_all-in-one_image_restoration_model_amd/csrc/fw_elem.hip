@@ -137,6 +137,7 @@ template <> struct Raw4<float> {
     FW_MEM void load(const float* p) { v = *reinterpret_cast<const uint4*>(p); }
     FW_MEM void lds(const char* p) { v = *reinterpret_cast<const uint4*>(p); }
     FW_MEM void zero_unless(bool ok) { if (!ok) v = make_uint4(0, 0, 0, 0); }
+    FW_MEM void launder() { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
     FW_MEM void unpack(float* f) const { unpack16<float>(v, f); }
 };
 template <> struct Raw4<bf16raw> {
@@ -144,6 +145,7 @@ template <> struct Raw4<bf16raw> {
     FW_MEM void load(const bf16raw* p) { v = *reinterpret_cast<const uint2*>(p); }
     FW_MEM void lds(const char* p) { v = *reinterpret_cast<const uint2*>(p); }
     FW_MEM void zero_unless(bool ok) { if (!ok) v = make_uint2(0, 0); }
+    FW_MEM void launder() { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
     FW_MEM void unpack(float* f) const {
         f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
         f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
@@ -455,6 +457,123 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
     }
 }
 
+// Forward stencil as a PERSISTENT tile loop (the scheme of dwconv_bwd_fused_kernel below): a workgroup walks NT vertically consecutive
+// 8 x 16 x 64-channel tiles, the next tile's halo pieces are in flight (registers) while the current one is computed from LDS, the
+// per-piece address arithmetic is done once per workgroup, the 9 x 64 weights live in LDS (one float4 per tap and thread).
+template <typename T, bool GIN>
+__global__ __launch_bounds__(256, 3) void dwconv_fwd_pipe_kernel(const T* __restrict__ in, long ldi, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              T* __restrict__ out, T* __restrict__ out2, long ldo, int B, int H, int W, int C, int NT) {
+    constexpr int SZ = TT<T>::SZ, E16 = TT<T>::E16;
+    constexpr int PXB = DT_CB * SZ, ROWB = (DT_TX + 2) * PXB + 128, CHUNKS = PXB / 16;
+    constexpr int NPIECE = (DT_TY + 2) * (DT_TX + 2) * CHUNKS, NI = (NPIECE + 255) / 256;
+    constexpr int TILEB = (DT_TY + 2) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int ncb = (C + DT_CB - 1) / DT_CB, ntx = (W + DT_TX - 1) / DT_TX, nty = H / DT_TY;
+    const int ncol = ncb * ntx;
+    const long nrow = (long)B * nty, nchunk = (nrow + NT - 1) / NT;
+    long bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int col = (int)(bid % ncol);
+    const long chunk = bid / ncol;
+    if (chunk >= nchunk) return;
+    const int cb = col % ncb, tx = col / ncb;
+    const long s0 = chunk * NT, s1 = s0 + NT < nrow ? s0 + NT : nrow;
+    const int x0 = tx * DT_TX, c0b = cb * DT_CB;
+    int ppack[NI], pxo[NI];
+    unsigned pokm = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int ch = idx % CHUNKS, px = (idx / CHUNKS) % (DT_TX + 2), row = (idx / (CHUNKS * (DT_TX + 2))) % (DT_TY + 2);
+        int xx = x0 + px - 1, cc = c0b + ch * E16;
+        if (idx < NPIECE && xx >= 0 && xx < W && cc + E16 <= C) pokm |= 1u << i;
+        xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx); cc = cc + E16 <= C ? cc : 0;
+        pxo[i] = xx * (int)ldi + cc; ppack[i] = (row * ROWB + px * PXB + ch * 16) | (row << 24);
+    }
+    const int cv = threadIdx.x & 15, ry = (threadIdx.x >> 4) & 7, sxl = threadIdx.x >> 7;
+    const int c0 = c0b + cv * 4;
+    const bool c_ok = c0 + 4 <= C;
+    const int cw = c_ok ? c0 : 0;
+    const int ox0 = x0 + sxl * 8;
+    float* wl = reinterpret_cast<float*>(dsm + TILEB);                  // [9][64]
+    for (int i = threadIdx.x; i < 9 * DT_CB; i += 256) {
+        const int c = c0b + (i % DT_CB);
+        wl[i] = c < C ? w[(i / DT_CB) * C + c] : 0.f;
+    }
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + cw);
+    const int rowelems = W * (int)ldi;
+    uint4 r[NI];
+    auto issue = [&](long s) {
+        const T* base = in + (s / nty) * H * (long)rowelems;
+        const int y0 = (int)(s % nty) * DT_TY;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int yy = y0 + (ppack[i] >> 24) - 1;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            r[i] = *reinterpret_cast<const uint4*>(base + (yy * rowelems + pxo[i]));
+        }
+    };
+    issue(s0);
+    for (long s = s0; s < s1; ++s) {
+        const long b = s / nty;
+        const int y0 = (int)(s % nty) * DT_TY;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (threadIdx.x + i * 256 >= NPIECE) continue;
+            const int yy = y0 + (ppack[i] >> 24) - 1;
+            uint4 piece = r[i];
+            if constexpr (GIN) {                              // the pre-activation arrives: GELU once per halo element, on its way into LDS
+                float f[E16];
+                unpack16<T>(piece, f);
+#pragma unroll
+                for (int e = 0; e < E16; ++e) f[e] = gelu_t<T>(f[e]);
+                piece = pack16<T>(f);
+            }
+            *reinterpret_cast<uint4*>(dsm + (ppack[i] & 0xffffff)) = (((pokm >> i) & 1) && yy >= 0 && yy < H) ? piece : make_uint4(0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                // one piece at a time: the scheduler otherwise unpacks all six at once (212 VGPRs)
+        }
+        __syncthreads();
+        if (s + 1 < s1) issue(s + 1);                         // in flight while this tile is computed
+        float acc[8][4];
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[o][e] = b4[e];
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+            const char* rowp = dsm + (ry + ky) * ROWB + (sxl * 8) * PXB + cv * 4 * SZ;
+            f32x4 wk[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) wk[kx] = *reinterpret_cast<const f32x4*>(wl + (ky * 3 + kx) * DT_CB + cv * 4);
+#pragma unroll
+            for (int cx = 0; cx < 10; ++cx) {
+                Raw4<T> q;
+                q.lds(rowp + cx * PXB);
+                float f[4];
+                q.unpack(f);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int o = cx - kx;
+                    if (o >= 0 && o < 8) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[o][e] += f[e] * wk[kx][e];
+                    }
+                }
+            }
+        }
+        const long tok0 = ((b * H + y0 + ry) * W + ox0) * ldo + c0;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const bool ok = c_ok && ox0 + o < W;
+            if (ok) stvec4<T>(out + tok0 + (long)o * ldo, acc[o]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[o][e] = gelu_t<T>(acc[o][e]);
+            if (ok) stvec4<T>(out2 + tok0 + (long)o * ldo, acc[o]);
+        }
+        __syncthreads();
+    }
+}
+
 // Whole backward of the depthwise 3x3 in ONE pass over its operands (dh2 and h1 read once, dh1 written once; the two-kernel form read
 // dh2 and h1 twice -- 5 tensor passes instead of 3 -- and evaluated the 30-tap gather twice).  Both gradients gather the SAME
 // neighbourhood of dh2 around an input pixel p:
@@ -546,7 +665,6 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_fused_kernel(const T* __res
             *reinterpret_cast<uint4*>(dsm + (ppack[i] & 0xffffff)) = (((pokm >> i) & 1) && yy >= 0 && yy < H) ? r[i] : make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
-        if (s + 1 < s1) issue_halo(s + 1);                    // in flight while this tile is computed
         float g[8][4], acc[8][4];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -555,6 +673,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_fused_kernel(const T* __res
             const bool in = ox0 + o < W;                     // a strip pixel beyond the image edge contributes nothing
 #pragma unroll
             for (int e = 0; e < 4; ++e) { g[o][e] = in ? gelu_t<T>(hc[e]) : 0.f; acc[o][e] = 0.f; }
+            if (o & 1) __builtin_amdgcn_sched_barrier(0);       // eight polynomials at a time, not thirty-two (their temporaries are registers)
         }
 #pragma unroll 1
         for (int ky = 0; ky < 3; ++ky) {
@@ -589,20 +708,27 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_fused_kernel(const T* __res
                         }
                     }
                 }
+                if (cx == 4) __builtin_amdgcn_sched_barrier(0);   // two batches of five LDS reads per row, not all thirty of a tile at once
             }
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) part[((ky * 3 + kx) * 4 + e) * 256 + threadIdx.x] += gk[kx][e];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < s1) issue_halo(s + 1);                    // the next halo flies under the epilogue (its registers are the ones g[] just left)
+        __builtin_amdgcn_sched_barrier(0);
         T* orow = dh1 + ((b * H + y0 + ry) * W + ox0) * ldo + c0;
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             float hc[4];
-            pre[o].unpack(hc);
+            Raw4<T> again = pre[o];
+            again.launder();                                  // a fresh unpack here: otherwise the 32 floats unpacked for GELU stay live across the stencil
+            again.unpack(hc);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[o][e] *= gelu_grad_t<T>(hc[e]);
             if (c_ok && ox0 + o < W) stvec4<T>(orow + (long)o * ldo, acc[o]);
+            if (o & 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (s + 1 < s1) issue_pre(s + 1);                     // h1 of the next tile: in flight across the barrier and the LDS staging
         __syncthreads();                                      // every wave is done with the tile before the next one overwrites it
@@ -1174,6 +1300,27 @@ extern "C" int fw_dwconv_fwd(int dtype, const void* g1, long ld1, int in_gelu, c
     FW_CHECK_ARG(g1 && w && bias && h2 && g2 && C % e == 0 && ld1 % e == 0 && ld2 % e == 0 && W % SX == 0);
     const long n = (long)B * H * (W / SX) * (C / 4);
     // the LDS-tiled form wins where the tensors outgrow the 256 MB infinity cache (stage-0 layers); below that the strips are as fast
+    static const int piped = getenv("FW_DWCONV_PIPE_FWD") ? atoi(getenv("FW_DWCONV_PIPE_FWD")) : 1;
+    if (piped && dw_tiled() && H % DT_TY == 0 && (long)B * H * W * C >= dw_tiled_min() && (long)H * W * ld1 < (1L << 31)) {
+        static const long want = getenv("FW_DWCONV_PIPE_WGS") ? atol(getenv("FW_DWCONV_PIPE_WGS")) : 2048;
+        const long ncol = (long)((C + DT_CB - 1) / DT_CB) * ((W + DT_TX - 1) / DT_TX), nrow = (long)B * (H / DT_TY);
+        long NT = ncol * nrow / want;
+        NT = NT < 1 ? 1 : (NT > 32 ? 32 : NT);
+        long nb = ncol * ((nrow + NT - 1) / NT);
+        nb = (nb + 7) / 8 * 8;
+        const size_t esz = dtype == FW_DT_BF16 ? 2 : 4;
+        const size_t lds = (size_t)(DT_TY + 2) * ((DT_TX + 2) * DT_CB * esz + 128) + 9 * DT_CB * sizeof(float);
+#define FW_PIPE_FWD(TY, GI)                                                                                                             \
+    do {                                                                                                                                \
+        FW_SET_LDS_ONCE((dwconv_fwd_pipe_kernel<TY, GI>), lds);                                                                         \
+        hipLaunchKernelGGL((dwconv_fwd_pipe_kernel<TY, GI>), dim3((unsigned)nb), dim3(256), lds, ST, (const TY*)g1, ld1, w, bias, (TY*)h2, \
+                           (TY*)g2, ld2, B, H, W, C, (int)NT);                                                                          \
+    } while (0)
+        if (dtype == FW_DT_BF16) { if (in_gelu) FW_PIPE_FWD(bf16raw, true); else FW_PIPE_FWD(bf16raw, false); }
+        else { if (in_gelu) FW_PIPE_FWD(float, true); else FW_PIPE_FWD(float, false); }
+#undef FW_PIPE_FWD
+        FW_LAUNCH_RET();
+    }
     if (dw_tiled() && H % DT_TY == 0 && (long)B * H * W * C >= dw_tiled_min()) {
         if (dtype == FW_DT_BF16)
             return in_gelu ? dwconv_tile_launch<bf16raw, 0, true>((const bf16raw*)g1, ld1, w, bias, (const bf16raw*)nullptr, (bf16raw*)h2, (bf16raw*)g2, ld2, B, H, W, C, ST)

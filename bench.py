@@ -201,7 +201,7 @@ def gemm_profile(engine, batch, reps=8):
                 fl += 2.0 * n * k * m
                 by += (n * m + k * m) * sz + n * k * osz + (n * osz if has_b else 0)
                 sk = max(1, -(-m // chunk))
-                over += n * k * osz * ((2 * sk - 1) if sk > 1 else 1)     # sliced: slab writes + fold reads; whole: the RMW read of dW
+                over += n * k * osz * ((2 * sk - 1) if sk > 1 else (0 if ops._GROUP_PLAIN else 1))   # sliced: slab writes + fold reads; whole: the RMW read of dW unless stored plainly (sole writer of a pre-zeroed gradient)
         nprob = sum(len(p) for p, _ in runs[:per_step])
         kern = 'gemm_wgrad_group_big_kernel' if tile == 256 else 'gemm_wgrad_group_kernel'
         # one row per tile form: "launch" = the mean of its launches of a step; FLOPs / bytes per launch likewise

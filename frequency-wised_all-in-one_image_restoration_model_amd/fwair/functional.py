@@ -230,7 +230,8 @@ def _wgrad(g, x, n, k, m, weight, bias=None):
     same pass (xsum).  Returns the autograd values (dW, db)."""
     dw, rw = _grad_target(weight, (n, k))
     db, rb = _grad_target(bias) if bias is not None else (None, None)
-    ops.wgrad(g, x, n, k, m, dw, db, defer=rw is None and rb is None)      # persistent .grad views only: autograd copies what it is handed
+    direct = rw is None and rb is None                 # persistent .grad views (engine mode: zeroed before every pass): autograd copies what it is handed otherwise
+    ops.wgrad(g, x, n, k, m, dw, db, defer=direct, fresh=direct)
     return (rw.view_as(weight) if rw is not None else None), rb
 
 
@@ -433,7 +434,7 @@ class QKVFn(torch.autograd.Function):
         fused, w3 = ctx.fused
         dx = act_empty(M, K, x.dtype, x.device)
         if w3 is not None and config.direct_grads and 'gw' in fused:
-            ops.wgrad(dbuf[:, :3 * C], x, 3 * C, K, M, fused['gw'], fused['gb'], defer=True)
+            ops.wgrad(dbuf[:, :3 * C], x, 3 * C, K, M, fused['gw'], fused['gb'], defer=True, fresh=True)
             ops.dgrad(dbuf[:, :3 * C], w3, M, K, 3 * C, dx)          # split over the 3C reduction when the output has few tiles
             return dx, None, None, None, None, None
         dq, dkv = dbuf[:, :C], dbuf[:, Cp:]

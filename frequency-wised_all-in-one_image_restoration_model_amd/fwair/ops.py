@@ -155,15 +155,18 @@ def _fold_slabs():
 _GROUP = int(_os.environ.get('FW_WGRAD_GROUP', '1'))                # 0: one launch per product (round-2 behaviour)
 _GROUP_CHUNK = int(_os.environ.get('FW_WGRAD_CHUNK', '4096'))       # tokens per work item: longer reductions are cut into slices (sweep on MI355X: 1024: 298.6, 2048: 307.5, 4096: 305.6-308.7, 8192: 302.3, 16384: 281.3 images/s)
 _GROUP_BIG_MIN = int(_os.environ.get('FW_WGRAD_BIG_MIN', '224'))  # smallest output side that takes the 256 x 256 tile form
+_GROUP_PLAIN = int(_os.environ.get('FW_WGRAD_PLAIN', '1'))        # sole writer of a (pre-zeroed) gradient: plain store instead of accumulate
 _GROUP_UNIT_BX = int(_os.environ.get('FW_WGRAD_UNIT_BX', '1'))    # dY column blocks per work unit (see _launch_group)
 _pending_w = []          # (g, x, n, k, m, dw, db)
+_shared_dw = set()
+_fresh_dw = set()        # gradients the caller vouches are ZERO when the pass starts (engine mode) and that ONE product writes: plain store
 
 
 def _register_flush():
     task = torch._C._current_graph_task_id()
     if _flush_registered[0] != task:                       # a new backward pass (an earlier one may have died before its callback ran)
         if _flush_registered[0] is not None:
-            _pending.clear(); _pending_w.clear()           # work of a pass that never finished: its gradients are void anyway
+            _pending.clear(); _pending_w.clear(); _fresh_dw.clear()      # work of a pass that never finished: its gradients are void anyway
         _flush_registered[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(flush_slabs)
 
@@ -182,6 +185,12 @@ def _flush_wgrads():
         return
     work = list(_pending_w)
     _pending_w.clear()
+    seen = set()
+    _shared_dw.clear()
+    for w_ in work:                                          # gradients that several products of this pass add into keep the accumulate form
+        (_shared_dw if w_[5].data_ptr() in seen else seen).add(w_[5].data_ptr())
+    _shared_dw.update(seen - _fresh_dw)                      # ... and so does everything nobody declared fresh
+    _fresh_dw.clear()
     # outputs of at least _GROUP_BIG_MIN rows and columns run on 256 x 256 tiles (8 waves), the others on 128 x 128 (4 waves)
     big = [w for w in work if min(w[2], w[3]) >= _GROUP_BIG_MIN]
     small = [w for w in work if min(w[2], w[3]) < _GROUP_BIG_MIN]
@@ -205,8 +214,9 @@ def _launch_group(work, tile=128):
         kper = -(-(-(-m // sk)) // 32) * 32                   # tokens per slice, whole 32-token steps
         sk = -(-m // kper)
         if sk == 1:
+            sole = dw.data_ptr() not in _shared_dw                      # fresh, and the only product of the pass that writes it
             rows.append((g.data_ptr(), x.data_ptr(), dw.data_ptr(), g.stride(0), x.stride(0), dw.stride(0), n, k, m, kper, 1,
-                         db.data_ptr() if db is not None else 0, 0, 0, 1, 0))
+                         db.data_ptr() if db is not None else 0, 1 if sole else 0, 0, 0 if sole else 1, 0))   # c_zstride > 0 selects the plain-store tile
         else:
             nk = (n * k + 3) // 4 * 4
             S = nk + (n + 3) // 4 * 4
@@ -253,14 +263,18 @@ def _launch_group(work, tile=128):
     # `work` (the operands) dies here: the allocator reuses them stream-ordered, i.e. after the kernel above
 
 
-def wgrad(g, x, n, k, m, dw, db=None, defer=False):
+def wgrad(g, x, n, k, m, dw, db=None, defer=False, fresh=False):
     """dw[n][k] += sum_m g[m][n] x[m][k];  db[n] += sum_m g[m][n].  With defer (dw / db are persistent gradient buffers nobody reads
     before the optimizer step) inside a backward pass the product is QUEUED and runs in the pass's grouped launch (_flush_wgrads).
+    fresh: the caller vouches that dw / db are ZERO when the pass starts (the engine's flat gradient buffer): if this is the only queued
+    product of the pass that writes them, its tiles are STORED instead of read-modified-written.
     Otherwise: large reductions are split over K into a slab of partial tiles (plain stores) that a slab reduce folds -- no
     same-address atomics."""
     if defer and _in_backward() and _groupable(g, x, n, k, m, dw, db):
         _register_flush()
         _pending_w.append((g, x, n, k, m, dw, db))
+        if fresh and _GROUP_PLAIN:
+            _fresh_dw.add(dw.data_ptr())
         return
     sk = pick_splitk(n, k, m, g.dtype)
     if sk == 1:

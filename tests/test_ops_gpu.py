@@ -347,6 +347,16 @@ def test_attention_encoder(dtype, L, mode, shift):
     close(dbias, tables.grad, tol, 'dbias tables')
 
 
+@pytest.mark.parametrize('rows,cols,ld', [(70000, 28, 64), (262144, 28, 56), (4099, 224, 224), (513, 512, 512), (1000, 516, 520), (300, 30, 32)])
+def test_colsum(rows, cols, ld):
+    """fw_colsum (bias gradients): the float4 form for narrow matrices (cols % 4 == 0, <= 512) and the plain form otherwise; ADDS into out."""
+    x = rnd(rows, ld, seed=7)[:, :cols]
+    out0 = rnd(cols, seed=8)
+    out = out0.clone().to(DEV)
+    ops().colsum(x.to(DEV)[:, :cols] if ld == cols else x.to(DEV), out)
+    close(out, out0.double() + x.double().sum(0), 2e-5, f'colsum {rows}x{cols}')
+
+
 # ------------------------------------------------------------------------------------------------ LeFF dwconv
 @pytest.mark.parametrize('twin', [True, False])
 @pytest.mark.parametrize('dtype', DTYPES)

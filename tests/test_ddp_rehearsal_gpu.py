@@ -39,13 +39,15 @@ def test_plain_bench_gpus_2_launches_its_own_ranks():
     env = dict(os.environ, FW_DIST_BACKEND='gloo', FW_DIST_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
+    # the data of BASELINE configs[3]: the five tasks (denoise 15 / 25 / 50, derain, dehaze) cycled over a per-rank batch of 5
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '5', '--tasks', 'allinone',
            '--no-cpu-baseline', '--no-profile']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, 'rank 0 prints exactly one JSON line'
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 4
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 10
+    assert 'configs[2]' in d['config']['workload'] and 'all-in-one' in d['config']['workload']
     assert d['config']['hip_graph'] is True
     assert all(math.isfinite(v) for v in d['loss'].values())

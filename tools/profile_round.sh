@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe of a round, run ON THE GPU BOX (through gpurun) from the repository root:
-#     bash tools/profile_round.sh r02 [commit]
+#     bash tools/profile_round.sh r03 [commit]
 #   1. rocprofv3 --kernel-trace --stats of the bench command          -> gpurun_out/<tag>_stats/  (+ profiles/<tag>_kernel_stats.csv)
 #   2. rocprofv3 --pmc FETCH_SIZE, its own run (kernel trace only)    -> gpurun_out/<tag>_pmc_fetch/
 #   3. rocprofv3 --pmc WRITE_SIZE, its own run                        -> gpurun_out/<tag>_pmc_write/
@@ -11,7 +11,7 @@
 # (gpurun_out/pmc_write3.log of round 1); a single-stream graph has the same kernels and the same bytes per launch.
 # Steps are chained with && : after a failure no further GPU step runs.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out

@@ -582,13 +582,14 @@ def test_frequency_decompose_backward(kind, size, inverse):
 
 # ------------------------------------------------------------------------------------------------ encoder head
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_bn_lrelu_gap(dtype):
-    B, ED, P = 4, 8, 16384
+@pytest.mark.parametrize('P', [16384, 1000])          # whole 16-byte strides (the vector form of the statistic passes) / the scalar form
+def test_bn_lrelu_gap(dtype, P):
+    B, ED = 4, 8
     fea = q(rnd(B, ED, P) * 1.5 + 0.2, dtype).requires_grad_(True)
     g, b = (1 + 0.1 * rnd(ED, seed=1)).requires_grad_(True), (0.1 * rnd(ED, seed=2)).requires_grad_(True)
     rm, rv = rnd(ED, seed=3) * 0.1, 1 + rnd(ED, seed=4).abs() * 0.1
     bn_rm, bn_rv = rm.clone(), rv.clone()
-    ref = F.leaky_relu(F.batch_norm(fea.view(B, ED, 128, 128), bn_rm, bn_rv, g, b, True, 0.1, 1e-5), 0.1).mean((2, 3))
+    ref = F.leaky_relu(F.batch_norm(fea.view(B, ED, P, 1), bn_rm, bn_rv, g, b, True, 0.1, 1e-5), 0.1).mean((2, 3))
     rmd, rvd = rm.to(DEV).clone(), rv.to(DEV).clone()
     nbt = torch.zeros((), dtype=torch.long, device=DEV)
     part, saved, gap = torch.empty(ED, B, 2, device=DEV), torch.empty(ED, 2, device=DEV), torch.empty(B, ED, device=DEV)
@@ -613,7 +614,7 @@ def test_bn_lrelu_gap(dtype):
     gap2 = torch.empty(B, ED, device=DEV)
     call('fw_bn_lrelu_gap_fwd', 1 if dtype == torch.bfloat16 else 0, fd, g.detach().to(DEV), b.detach().to(DEV), rmd, rvd, nbt,
          None, None, gap2, B, ED, P, 0, 1e-5, 0.1, 0.1)
-    ref2 = F.leaky_relu(F.batch_norm(fea.detach().view(B, ED, 128, 128), bn_rm, bn_rv, g.detach(), b.detach(), False, 0.1, 1e-5), 0.1).mean((2, 3))
+    ref2 = F.leaky_relu(F.batch_norm(fea.detach().view(B, ED, P, 1), bn_rm, bn_rv, g.detach(), b.detach(), False, 0.1, 1e-5), 0.1).mean((2, 3))
     close(gap2, ref2, 2e-4, 'gap eval')
 
 
